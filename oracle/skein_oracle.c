@@ -1,0 +1,153 @@
+/*
+ * skein_oracle.c -- TEST INFRASTRUCTURE: CPU restatement of Skein-256/-512 as the
+ * reference vendors it (2008 NIST round-1 submission: rotation constants of
+ * reference_code/skein/Optimized_64bit/skein.h:275-292, key-schedule parity
+ * 0x5555555555555555 skein.h:196 -- NOT the later Skein 1.2/1.3 constants).
+ *
+ * Written in the textbook Threefish form (MIX on adjacent word pairs, then a word
+ * permutation) rather than the reference's operand-renamed unrolled form; the
+ * two are equivalent (reference loop form: Reference_Implementation/skein_block.c:127-219,
+ * key injection :29-35; API: Optimized_64bit/skein.c:226-266 Init, :329-373 Update,
+ * :377-408 Final; bit padding: KAT_MCT/src/SHA3api_ref.c Update()).
+ *
+ * Pinned by tests/test_oracle_skein.py against the reference's KAT files and
+ * against oracle/_ref/libskein_ref.so (the reference's own C compiled in place).
+ */
+#include "cw_oracle.h"
+#include <string.h>
+
+#define T1_FIRST   (1ULL << 62)
+#define T1_FINAL   (1ULL << 63)
+#define T1_BITPAD  (1ULL << 55)
+#define T1_TYPE(t) ((uint64_t)(t) << 56)
+enum { TYPE_CFG = 4, TYPE_MSG = 48, TYPE_OUT = 63 };
+
+#define KS_PARITY 0x5555555555555555ULL
+#define SCHEMA_VER ((1ULL << 32) | 0x33414853ULL) /* version 1, "SHA3" */
+
+/* rotation amounts, [round mod 8][pair] */
+static const unsigned char ROT4[8][2] = {
+    {5, 56}, {36, 28}, {13, 46}, {58, 44}, {26, 20}, {53, 35}, {11, 42}, {59, 50}};
+static const unsigned char ROT8[8][4] = {
+    {38, 30, 50, 53}, {48, 20, 43, 31}, {34, 14, 15, 27}, {26, 12, 58, 7},
+    {33, 49, 8, 42},  {39, 27, 41, 14}, {29, 26, 11, 9},  {33, 51, 39, 35}};
+/* word permutation applied after each round: new[i] = old[PERM[i]] */
+static const unsigned char PERM4[4] = {0, 3, 2, 1};
+static const unsigned char PERM8[8] = {2, 1, 4, 7, 6, 5, 0, 3};
+
+static inline uint64_t rotl64(uint64_t x, unsigned r) { return (x << r) | (x >> (64 - r)); }
+
+static uint64_t load_le64(const uint8_t *p)
+{
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; i--) v = (v << 8) | p[i];
+    return v;
+}
+
+/*
+ * One UBI step: chain <- Threefish_{chain, tweak}(block) XOR block.
+ * nw = 4 or 8 state words, 72 rounds, a subkey every 4 rounds.
+ */
+static void ubi_block(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const uint8_t *block)
+{
+    uint64_t ks[9], ts[3], w[8], v[8], tmp[8];
+    int i, d, s;
+
+    ks[nw] = KS_PARITY;
+    for (i = 0; i < nw; i++) { ks[i] = chain[i]; ks[nw] ^= chain[i]; }
+    ts[0] = t0; ts[1] = t1; ts[2] = t0 ^ t1;
+    for (i = 0; i < nw; i++) { w[i] = load_le64(block + 8 * i); v[i] = w[i]; }
+
+    for (d = 0; d < 72; d++) {
+        if ((d & 3) == 0) { /* subkey s = d/4 */
+            s = d >> 2;
+            for (i = 0; i < nw; i++) v[i] += ks[(s + i) % (nw + 1)];
+            v[nw - 3] += ts[s % 3];
+            v[nw - 2] += ts[(s + 1) % 3];
+            v[nw - 1] += (uint64_t)s;
+        }
+        for (i = 0; i < nw / 2; i++) {
+            unsigned r = (nw == 4) ? ROT4[d & 7][i] : ROT8[d & 7][i];
+            v[2 * i] += v[2 * i + 1];
+            v[2 * i + 1] = rotl64(v[2 * i + 1], r) ^ v[2 * i];
+        }
+        for (i = 0; i < nw; i++) tmp[i] = v[(nw == 4) ? PERM4[i] : PERM8[i]];
+        memcpy(v, tmp, sizeof(uint64_t) * (size_t)nw);
+    }
+    s = 18;
+    for (i = 0; i < nw; i++) v[i] += ks[(s + i) % (nw + 1)];
+    v[nw - 3] += ts[s % 3];
+    v[nw - 2] += ts[(s + 1) % 3];
+    v[nw - 1] += (uint64_t)s;
+
+    for (i = 0; i < nw; i++) chain[i] = v[i] ^ w[i];
+}
+
+void cw_oracle_skein_iv(int nw, unsigned hash_bits, uint64_t *iv)
+{
+    uint8_t cfg[64];
+    uint64_t words[3] = {SCHEMA_VER, hash_bits, 0 /* sequential, no tree */};
+    memset(cfg, 0, sizeof cfg);
+    for (int k = 0; k < 3; k++)
+        for (int b = 0; b < 8; b++) cfg[8 * k + b] = (uint8_t)(words[k] >> (8 * b));
+    memset(iv, 0, sizeof(uint64_t) * (size_t)nw);
+    /* config string is 32 bytes whatever the state size (skein.h SKEIN_CFG_STR_LEN) */
+    ubi_block(nw, iv, 32, T1_FIRST | T1_FINAL | T1_TYPE(TYPE_CFG), cfg);
+}
+
+static int skein_generic(int nw, const uint8_t *msg, size_t msg_bits, unsigned hash_bits, uint8_t *out)
+{
+    const size_t bb = (size_t)nw * 8; /* block bytes */
+    uint64_t chain[8], t0 = 0, t1 = T1_FIRST | T1_TYPE(TYPE_MSG);
+    uint8_t last[64];
+    size_t nbytes = (msg_bits + 7) >> 3, pos = 0, rem;
+    unsigned out_bytes = (hash_bits + 7) >> 3, produced = 0;
+    uint64_t ctr = 0;
+
+    if (hash_bits == 0) return -1;
+    cw_oracle_skein_iv(nw, hash_bits, chain);
+
+    /* all blocks but the last: a full final block is held back so FINAL lands on data */
+    while (nbytes - pos > bb) {
+        t0 += bb;
+        ubi_block(nw, chain, t0, t1, msg + pos);
+        t1 &= ~T1_FIRST;
+        pos += bb;
+    }
+    rem = nbytes - pos; /* 0 (empty message only) .. bb */
+    memset(last, 0, sizeof last);
+    if (rem) memcpy(last, msg + pos, rem);
+    if (msg_bits & 7) { /* partial final byte: keep the top bits, append a 1 bit */
+        uint8_t mask = (uint8_t)(1u << (7 - (msg_bits & 7)));
+        last[rem - 1] = (uint8_t)((last[rem - 1] & (uint8_t)(0 - mask)) | mask);
+        t1 |= T1_BITPAD;
+    }
+    t0 += rem;
+    ubi_block(nw, chain, t0, t1 | T1_FINAL, last);
+
+    /* output: Threefish in counter mode keyed by the final chaining value */
+    while (produced < out_bytes) {
+        uint64_t o[8];
+        uint8_t cblk[64];
+        unsigned n = out_bytes - produced;
+        memcpy(o, chain, sizeof o);
+        memset(cblk, 0, sizeof cblk);
+        for (int b = 0; b < 8; b++) cblk[b] = (uint8_t)(ctr >> (8 * b));
+        ubi_block(nw, o, 8, T1_FIRST | T1_FINAL | T1_TYPE(TYPE_OUT), cblk);
+        if (n > bb) n = (unsigned)bb;
+        for (unsigned k = 0; k < n; k++) out[produced + k] = (uint8_t)(o[k >> 3] >> (8 * (k & 7)));
+        produced += n;
+        ctr++;
+    }
+    return 0;
+}
+
+int cw_oracle_skein512(const uint8_t *msg, size_t msg_bits, unsigned hash_bits, uint8_t *out)
+{
+    return skein_generic(8, msg, msg_bits, hash_bits, out);
+}
+
+int cw_oracle_skein256(const uint8_t *msg, size_t msg_bits, unsigned hash_bits, uint8_t *out)
+{
+    return skein_generic(4, msg, msg_bits, hash_bits, out);
+}
