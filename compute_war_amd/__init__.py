@@ -1,0 +1,14 @@
+"""compute-war_amd: MI355X-native back end for compute-war's per-block hash + compress hot path.
+
+The product is ``libcwhc.so`` (hand-written HIP kernels for gfx950 behind the C ABI declared in
+``include/cw_hashcompress.h``).  This package is the thin host-side mirror of the reference's operator
+interface (``doHashing`` / ``doCompression`` slots, ``HashOffload``) over that ABI via ctypes.
+There is no CPU fallback: without the built library and a gfx950 device every compute call raises.
+"""
+from ._lib import (COMP_LZ4, COMP_LZF, COMP_NONE, HASH_NONE, HASH_SHA256, HASH_SKEIN256_128, HASH_SKEIN512,
+                   CwError, lib, lib_path)
+from .ops import (HashOffload, compress_blocks, compress_bound, dev_compress, dev_gen_random, dev_hash,
+                  dev_hash_and_compress, dev_sum_sizes, digest_bytes, do_compression, do_hashing,
+                  hash_and_compress_blocks, hash_blocks, init, set_block_size, shutdown)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,35 @@
+// cw_device.h -- internal declarations shared by the HIP translation units of libcwhc.so.
+// Not part of the public boundary (that is include/cw_hashcompress.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef CW_SKEIN_THREADS
+#define CW_SKEIN_THREADS 64 // one wavefront per workgroup: lanes never communicate, small groups spread evenly
+#endif
+
+namespace cw {
+
+struct SkeinIV { uint64_t w[8]; };
+
+// host: chaining value after the configuration block (Skein_*_Init)
+void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv);
+
+// device launches (async on `stream`); src_stride = distance between consecutive blocks in bytes
+hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
+hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
+hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *digests,
+                         hipStream_t stream);
+hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
+                      size_t dst_stride, uint32_t *sizes, hipStream_t stream);
+hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
+                      size_t dst_stride, uint32_t *sizes, hipStream_t stream);
+hipError_t sum_sizes_launch(const uint32_t *sizes, size_t n, uint32_t raw_bytes, uint64_t *totals, hipStream_t stream);
+hipError_t gen_random_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
+                             hipStream_t stream);
+
+} // namespace cw

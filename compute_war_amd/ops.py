@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's operator interface over the C ABI.
+
+Names follow the reference: ``do_hashing(src, dst, count)`` / ``do_compression(src, dst, len)`` are the two
+function slots of src/hashandcompress/HashAndCompress.cpp:111,119; ``HashOffload`` is HashOffload.h:13-64.
+The ``dev_*`` functions take raw device pointers (ints, e.g. ``torch.Tensor.data_ptr()``) and a HIP stream
+handle; torch is only ever used by callers for memory and streams, never here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import COMP_LZ4, COMP_LZF, COMP_NONE, HASH_NONE, HASH_SKEIN256_128, HASH_SKEIN512, HASH_SHA256, check, lib
+
+_HASH_NAMES = {"skein": HASH_SKEIN256_128, "skein512": HASH_SKEIN512, "sha256mb": HASH_SHA256, "sha256": HASH_SHA256}
+_COMP_NAMES = {"lz4": COMP_LZ4, "lzf": COMP_LZF}
+
+
+def _hash_id(alg) -> int:
+    return _HASH_NAMES[alg] if isinstance(alg, str) else int(alg)
+
+
+def _comp_id(alg) -> int:
+    return _COMP_NAMES[alg] if isinstance(alg, str) else int(alg)
+
+
+def init(device: int = 0) -> None:
+    """initializeGpu() (HashAndCompress.cpp:95-98)."""
+    check(lib().cw_init(device))
+
+
+def shutdown() -> None:
+    lib().cw_shutdown()
+
+
+def set_block_size(n: int) -> None:
+    lib().cw_set_block_size(n)
+
+
+def digest_bytes(alg) -> int:
+    return int(lib().cw_digest_bytes(_hash_id(alg)))
+
+
+def compress_bound(alg, block_bytes: int) -> int:
+    return int(lib().cw_compress_bound(_comp_id(alg), block_bytes))
+
+
+def _np_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data.reshape(-1).view(np.uint8))
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+# ---- the two slots -------------------------------------------------------------------------------
+def do_hashing(alg, src, count: int, block_bytes: int | None = None) -> bytes:
+    """doHashing(src, dst, count): `count` consecutive blocks -> `count` consecutive digests."""
+    a = _np_u8(src)
+    if block_bytes is not None:
+        set_block_size(block_bytes)
+    hid = _hash_id(alg)
+    out = np.zeros(count * digest_bytes(hid), dtype=np.uint8)
+    fn = {HASH_SKEIN256_128: lib().cw_hash_skein, HASH_SKEIN512: lib().cw_hash_skein512,
+          HASH_SHA256: lib().cw_hash_sha256mb}[hid]
+    if a.size < count * int(lib().cw_get_block_size()):
+        raise ValueError("src shorter than count * block size")
+    fn(a.ctypes.data, out.ctypes.data, count)
+    return out.tobytes()
+
+
+def do_compression(alg, src) -> bytes:
+    """doCompression(src, dst, len) with the reference's dst capacity (2*len for lz4, len-1 for lzf);
+    b'' when the codec reports 0 (did not fit)."""
+    a = _np_u8(src)
+    cid = _comp_id(alg)
+    out = np.zeros(max(2 * a.size, 16), dtype=np.uint8)
+    fn = lib().cw_compress_lz4 if cid == COMP_LZ4 else lib().cw_compress_lzf
+    n = fn(a.ctypes.data, out.ctypes.data, a.size)
+    return out[:n].tobytes()
+
+
+# ---- batched host API ----------------------------------------------------------------------------
+def hash_blocks(alg, src, block_bytes: int) -> np.ndarray:
+    a = _np_u8(src)
+    n = a.size // block_bytes if block_bytes else 0
+    hid = _hash_id(alg)
+    out = np.zeros((n, digest_bytes(hid)), dtype=np.uint8)
+    check(lib().cw_hash_blocks(hid, a.ctypes.data, block_bytes, n, out.ctypes.data))
+    return out
+
+
+def compress_blocks(alg, src, block_bytes: int):
+    """Returns (sizes[n] uint32, payload[n, stride] uint8)."""
+    a = _np_u8(src)
+    n = a.size // block_bytes
+    cid = _comp_id(alg)
+    stride = compress_bound(cid, block_bytes)
+    payload = np.zeros((n, stride), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    check(lib().cw_compress_blocks(cid, a.ctypes.data, block_bytes, n, payload.ctypes.data, stride, sizes.ctypes.data))
+    return sizes, payload
+
+
+def hash_and_compress_blocks(hash_alg, comp_alg, src, block_bytes: int):
+    """ProcessBlock (:231-261) over every block of `src`: (digests, sizes, payload)."""
+    a = _np_u8(src)
+    n = a.size // block_bytes
+    hid, cid = _hash_id(hash_alg), _comp_id(comp_alg)
+    stride = compress_bound(cid, block_bytes)
+    digests = np.zeros((n, digest_bytes(hid)), dtype=np.uint8)
+    payload = np.zeros((n, stride), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    check(lib().cw_hash_and_compress_blocks(hid, cid, a.ctypes.data, block_bytes, n, digests.ctypes.data,
+                                            payload.ctypes.data, stride, sizes.ctypes.data))
+    return digests, sizes, payload
+
+
+# ---- device-resident API (raw pointers) ------------------------------------------------------------
+def dev_hash(alg, d_src: int, block_bytes: int, nblocks: int, d_digests: int, stream: int = 0,
+             src_stride: int | None = None) -> None:
+    check(lib().cw_dev_hash(_hash_id(alg), d_src, block_bytes, src_stride or block_bytes, nblocks, d_digests, stream))
+
+
+def dev_compress(alg, d_src: int, block_bytes: int, nblocks: int, d_dst: int, dst_stride: int, d_sizes: int,
+                 stream: int = 0, src_stride: int | None = None) -> None:
+    check(lib().cw_dev_compress(_comp_id(alg), d_src, block_bytes, src_stride or block_bytes, nblocks, d_dst, dst_stride,
+                                d_sizes, stream))
+
+
+def dev_hash_and_compress(hash_alg, comp_alg, d_src: int, block_bytes: int, nblocks: int, d_digests: int, d_dst: int,
+                          dst_stride: int, d_sizes: int, stream: int = 0, src_stride: int | None = None) -> None:
+    check(lib().cw_dev_hash_and_compress(_hash_id(hash_alg), _comp_id(comp_alg), d_src, block_bytes,
+                                         src_stride or block_bytes, nblocks, d_digests, d_dst, dst_stride, d_sizes, stream))
+
+
+def dev_gen_random(seed: int, first_block: int, nblocks: int, block_bytes: int, d_dst: int, stream: int = 0) -> None:
+    check(lib().cw_dev_gen_random(seed, first_block, nblocks, block_bytes, d_dst, stream))
+
+
+def dev_sum_sizes(d_sizes: int, nblocks: int, raw_bytes: int, d_totals: int, stream: int = 0) -> None:
+    check(lib().cw_dev_sum_sizes(d_sizes, nblocks, raw_bytes, d_totals, stream))
+
+
+# ---- HashOffload ------------------------------------------------------------------------------------
+class HashOffload:
+    """HashOffload.h:13-64: Reset(data, results, onComplete) -> Enqueue() -> Start() -> Complete()."""
+
+    hInit, hQueued, hOffloaded, hComplete = 0, 1, 2, 3
+
+    def __init__(self, n_blocks: int, alg="skein", block_bytes: int = 4096):
+        self._h = lib().cw_offload_create(_hash_id(alg), n_blocks, block_bytes)
+        if not self._h:
+            raise _lib.CwError(-2, lib().cw_last_error().decode())
+        self.n_blocks, self.block_bytes, self.alg = n_blocks, block_bytes, _hash_id(alg)
+        self._keep = None
+
+    def Reset(self, data: np.ndarray, results: np.ndarray, on_complete=None) -> None:
+        cb = _lib.ON_COMPLETE((lambda _arg: on_complete()) if on_complete else (lambda _arg: None))
+        self._keep = (data, results, cb)
+        check(lib().cw_offload_reset(self._h, data.ctypes.data, results.ctypes.data, cb, None))
+
+    def Enqueue(self) -> None:
+        check(lib().cw_offload_enqueue(self._h))
+
+    def Start(self) -> None:
+        check(lib().cw_offload_start(self._h))
+
+    def Complete(self) -> None:
+        check(lib().cw_offload_complete(self._h))
+
+    def Completed(self) -> bool:
+        return bool(lib().cw_offload_completed(self._h))
+
+    def DoOffload(self) -> None:
+        check(lib().cw_offload_do(self._h))
+
+    def Submit(self) -> None:
+        """Enqueue + hand to the offload thread (hashing_offload_entry_point, :160-183)."""
+        check(lib().cw_offload_submit(self._h))
+
+    @property
+    def state(self) -> int:
+        return int(lib().cw_offload_state(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            lib().cw_offload_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,143 @@
+/*
+ * cw_hashcompress.h -- C ABI of libcwhc.so: the MI355X (gfx950) back end for the reference's
+ * per-block hash + front-end compression hot path.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  Plain pointers and sizes only; no C++/torch types cross this line.
+ *
+ *   slots      doHashing / doCompression          src/hashandcompress/HashAndCompress.cpp:111,119
+ *   hashes     doSkeinHashing                     src/hashandcompress/HashAndCompress.cpp:121-134
+ *              doSHA256MBHashing                  src/hashandcompress/HashAndCompress.cpp:136-158
+ *              HashBlockSkein256/SHA256/SHA256MB  src/hashing_perf/hash.cpp:5-77
+ *   codecs     lz4 / lzf lambdas                  src/hashandcompress/HashAndCompress.cpp:342-355
+ *   GPU seam   initializeGpu()                    src/hashandcompress/HashAndCompress.cpp:95-98
+ *              class HashOffload                  src/hashandcompress/HashOffload.h:13-64
+ *              hashing_offload_entry_point        src/hashandcompress/HashAndCompress.cpp:160-183
+ *
+ * Threading: every function may be called concurrently from any number of host threads
+ * (the reference calls its slots from --c-threads workers, :398-402); each calling thread
+ * gets its own HIP stream and staging buffers.
+ *
+ * There is NO CPU fallback: every compute entry point fails (CW_ERR_NO_DEVICE / abort in the
+ * void slot wrappers) when no gfx950 device is usable.
+ */
+#ifndef CW_HASHCOMPRESS_H
+#define CW_HASHCOMPRESS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------------------------- */
+enum {
+    CW_OK = 0,
+    CW_ERR_NO_DEVICE = -1,   /* no usable HIP device / cw_init not possible */
+    CW_ERR_BAD_ARG = -2,     /* unknown algorithm, NULL pointer, size out of the supported range */
+    CW_ERR_HIP = -3,         /* a HIP runtime call failed; see cw_last_error() */
+    CW_ERR_STATE = -4,       /* offload object used out of order (HashOffload's asserts) */
+    CW_ERR_NOMEM = -5
+};
+
+/* --hash-alg values of the driver (:361-370) plus the north-star Skein-512-512 */
+typedef enum cw_hash_alg {
+    CW_HASH_SKEIN512 = 0,      /* Skein-512, 512-bit digest (reference_code/skein, skein.c:226-408) */
+    CW_HASH_SKEIN256_128 = 1,  /* "skein": Skein-256, 128-bit digest (kHashSizeBytesSkein=16, hash.h:16) */
+    CW_HASH_SHA256 = 2,        /* "sha256mb": FIPS 180-4 SHA-256 of each block (kHashSizeBytesSHA=32) */
+    CW_HASH_NONE = 3
+} cw_hash_alg;
+
+/* --comp-alg values of the driver (:342-355) */
+typedef enum cw_comp_alg {
+    CW_COMP_LZ4 = 0,           /* LZ4_compress_default(s, d, l, 2*l), LZ4 v1.8.2 */
+    CW_COMP_LZF = 1,           /* lzf_compress(s, l, d, l-1), liblzf HLOG 16 / VERY_FAST */
+    CW_COMP_NONE = 2
+} cw_comp_alg;
+
+/* ---- lifecycle: initializeGpu() (:95-98) and the shutdown hook (:182) ----------------------- */
+int  cw_init(int device);            /* select + warm the device; idempotent; CW_OK or CW_ERR_* */
+void cw_shutdown(void);
+int  cw_device_count(void);          /* usable gfx950 devices (0 when none) */
+const char *cw_last_error(void);     /* message of the calling thread's last failure */
+const char *cw_version(void);
+
+/* ---- sizes ---------------------------------------------------------------------------------- */
+size_t cw_digest_bytes(int hash_alg);                        /* 64 / 16 / 32 / 0 */
+size_t cw_compress_bound(int comp_alg, size_t block_bytes);  /* output slot a block may need:
+                                                                lz4: l + l/255 + 16 (LZ4_compressBound); lzf: l */
+#define CW_MAX_BLOCK_BYTES 65536u   /* LZ4's 16-bit-table regime of the reference (< 65547) */
+
+/* ---- the two slots, host pointers, synchronous -- drop-in for the reference's function objects --
+ * void doHashing(const char* src, char* dst, int count)  hashes `count` consecutive blocks of
+ * cw_get_block_size() bytes at src into count consecutive digests at dst (:121-133).
+ * size_t doCompression(const char* src, char* dst, size_t len) compresses one block; returns the
+ * compressed size, 0 = did not fit (lzf, lzf.h:59-64).  dst capacity is 2*len (lz4) / len-1 (lzf),
+ * as the reference's callers provide (:234-239, :346, :353).
+ * The void slots abort() with a message on a device error, since the reference's slots cannot
+ * report one (SURVEY.md 8b "Errors").                                                            */
+void   cw_set_block_size(size_t block_bytes);   /* the reference's global blockSize (:89), default 4096 */
+size_t cw_get_block_size(void);
+void   cw_hash_skein(const char *src, char *dst, int count);      /* doSkeinHashing: Skein-256-128 */
+void   cw_hash_skein512(const char *src, char *dst, int count);   /* Skein-512-512 */
+void   cw_hash_sha256mb(const char *src, char *dst, int count);   /* doSHA256MBHashing (digests ARE returned) */
+size_t cw_compress_lz4(const char *src, char *dst, size_t len);
+size_t cw_compress_lzf(const char *src, char *dst, size_t len);
+
+/* ---- batched host API: many blocks per call (H2D, kernels, D2H on the caller's stream) --------
+ * src: nblocks * block_bytes contiguous; digests: nblocks * cw_digest_bytes(); dst: nblocks slots of
+ * dst_stride >= cw_compress_bound(); sizes[i] = compressed bytes of block i (0 = did not fit).
+ * Any of digests / (dst,sizes) may be NULL to skip that half.  This is ProcessBlock (:231-261) for
+ * a whole read-unit or file at once.                                                              */
+int cw_hash_blocks(int hash_alg, const void *src, size_t block_bytes, size_t nblocks, void *digests);
+int cw_compress_blocks(int comp_alg, const void *src, size_t block_bytes, size_t nblocks,
+                       void *dst, size_t dst_stride, uint32_t *sizes);
+int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, size_t block_bytes,
+                                size_t nblocks, void *digests, void *dst, size_t dst_stride,
+                                uint32_t *sizes);
+
+/* ---- device-resident API: every pointer is device memory, work is queued on `stream`
+ *      (a hipStream_t passed as void*; NULL = the default stream) and NOT synchronised -----------
+ * src_stride = bytes between consecutive blocks (>= block_bytes).                                 */
+int cw_dev_hash(int hash_alg, const void *d_src, size_t block_bytes, size_t src_stride, size_t nblocks,
+                void *d_digests, void *stream);
+int cw_dev_compress(int comp_alg, const void *d_src, size_t block_bytes, size_t src_stride,
+                    size_t nblocks, void *d_dst, size_t dst_stride, uint32_t *d_sizes, void *stream);
+int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size_t block_bytes,
+                             size_t src_stride, size_t nblocks, void *d_digests, void *d_dst,
+                             size_t dst_stride, uint32_t *d_sizes, void *stream);
+/* synthetic input: u64 word w of block b = splitmix64(seed ^ (b << 13 | w)) */
+int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes,
+                      void *d_dst, void *stream);
+/* d_totals[0] += sum of sizes (a 0 counts as raw_bytes: stored uncompressed); d_totals[1] += #zeros */
+int cw_dev_sum_sizes(const uint32_t *d_sizes, size_t nblocks, uint32_t raw_bytes, uint64_t *d_totals,
+                     void *stream);
+
+/* ---- HashOffload (HashOffload.h:13-64): batch object + the offload thread that drains it -------
+ * Lifecycle  hInit --Enqueue--> hQueued --Start--> hOffloaded --Complete--> hComplete.
+ * Start() = "xfer data, load kernel" (:26-31): async H2D + hash kernel + async D2H on the object's stream.
+ * Complete() = "wait for and reap the results" (:33-40): blocks, then runs on_complete(arg).       */
+typedef struct cw_offload cw_offload_t;
+enum { CW_OFFLOAD_INIT = 0, CW_OFFLOAD_QUEUED = 1, CW_OFFLOAD_OFFLOADED = 2, CW_OFFLOAD_COMPLETE = 3 };
+
+cw_offload_t *cw_offload_create(int hash_alg, int n_blocks, size_t block_bytes);   /* HashOffload(int nBlocks) */
+void cw_offload_destroy(cw_offload_t *h);
+int  cw_offload_reset(cw_offload_t *h, char *data, char *results,
+                      void (*on_complete)(void *), void *arg);                     /* Reset(d, r, f) */
+int  cw_offload_enqueue(cw_offload_t *h);                                          /* Enqueue() */
+int  cw_offload_start(cw_offload_t *h);                                            /* Start() */
+int  cw_offload_complete(cw_offload_t *h);                                         /* Complete() */
+int  cw_offload_completed(const cw_offload_t *h);                                  /* Completed() */
+int  cw_offload_state(const cw_offload_t *h);
+int  cw_offload_do(cw_offload_t *h);                                               /* DoOffload() */
+
+/* hashing_offload_entry_point (:160-183): one consumer thread popping a queue of HashOffload* */
+int  cw_offload_thread_start(void);
+int  cw_offload_submit(cw_offload_t *h);   /* Enqueue() + push + notify (the producer the reference never wrote) */
+void cw_offload_thread_stop(void);         /* allWorkFinished = true; join */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CW_HASHCOMPRESS_H */
