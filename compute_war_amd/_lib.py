@@ -30,11 +30,34 @@ class CwError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libcwhc.so")
+    # CW_LIB lets kernel experiments load an alternative build of the same ABI
+    return os.environ.get("CW_LIB") or os.path.join(_HERE, "libcwhc.so")
 
 
 _lib = None
 ON_COMPLETE = C.CFUNCTYPE(None, C.c_void_p)
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """A PyTorch-ROCm wheel bundles its own libamdhip64/libhsa-runtime64.  If libcwhc.so pulled in
+    /opt/rocm's copies first, a later ``import torch`` would load a SECOND HSA runtime into the process and
+    see no GPU.  When such a wheel is installed (and torch is not imported yet), load its runtime first so
+    both sides share one; without torch the system ROCm runtime is used as linked."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
 
 
 def lib() -> C.CDLL:
@@ -46,6 +69,7 @@ def lib() -> C.CDLL:
     if not os.path.exists(path):
         raise CwError(-1, f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                           "g.build()'); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     vp, sz, u32p = C.c_void_p, C.c_size_t, C.c_void_p
     sigs = {
