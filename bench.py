@@ -49,13 +49,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: affinity mask, cgroup quota, and the pool's stated share of a
+    1-GPU box (16) -- os.cpu_count() reports every core of the host."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(args, target_s: float):
     """Oracle (CPU restatement of the reference's worker loop) on a bounded sample of the same workload."""
     import numpy as np
 
     import oracle as O
     O.build()
-    threads = os.cpu_count() or 1
+    threads = host_cpu_share()
     bs = args.block_bytes
     h = {"skein512": O.HASH_SKEIN512, "skein": O.HASH_SKEIN256_128, "sha256mb": O.HASH_SHA256}[args.hash]
     c = {"lz4": O.COMP_LZ4, "lzf": O.COMP_LZF}[args.comp]

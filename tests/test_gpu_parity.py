@@ -259,9 +259,20 @@ def test_full_size_properties(cw, oracle):
     cw.dev_hash_and_compress("skein512", "lz4", src.data_ptr(), bs, nb, dig.data_ptr(), dst.data_ptr(), stride,
                              sizes.data_ptr(), s)
     torch.cuda.synchronize()
-    assert bool((sizes == 65794).all())
+    # almost every random block is stored raw (65,794 B); about 1 in 1000 holds a chance 4-byte repeat among
+    # its ~2.9 k probes and gets a real match -- those blocks are checked against the oracle byte for byte
+    hz = sizes.cpu().numpy()
+    odd = np.nonzero(hz != 65794)[0]
+    assert len(odd) < nb // 100
+    for i in odd[:64]:
+        blk = oracle.gen_random_blocks(0xC0FFEE, int(i), 1, bs)
+        want = oracle.lz4_compress(blk)
+        assert hz[i] == len(want) and dst[i * stride:i * stride + len(want)].cpu().numpy().tobytes() == want, int(i)
+    raw = [int(i) for i in (0, 1, 63, 64, 4097, nb - 1) if hz[i] == 65794]
     hd = dig.cpu().numpy()
     for i in (0, 1, 63, 64, 4097, nb - 1):
+        assert hd[i].tobytes() == oracle.skein512(oracle.gen_random_blocks(0xC0FFEE, i, 1, bs), 512)
+    for i in raw:
         blk = oracle.gen_random_blocks(0xC0FFEE, i, 1, bs)
         assert hd[i].tobytes() == oracle.skein512(blk, 512)
         out = dst[i * stride:i * stride + 65794].cpu().numpy()
