@@ -20,9 +20,19 @@
 //   * backward/forward match extension: 64 byte compares per step, ballot + count-trailing-ones;
 //   * literal copies and length-byte runs: 16 B per lane, 1 KiB per wavefront instruction.
 // Output goes straight to the block's slot in HBM (dst + i*dst_stride); sizes[i] receives the length.
+//
+// Two kernels per call.  (1) lz4_scan_kernel runs, for every block, exactly the probe sequence the serial
+// parser performs while it finds NO match (positions depend only on the skip schedule).  If no probe's
+// candidate matches, the parser's output is fully determined -- one literal run -- and the scan kernel
+// writes it and is done with the block: that is every incompressible block, at a small fraction of the
+// cost of a real parse and with only the table (no block copy) in LDS, i.e. 5 instead of 2 blocks per CU.
+// The first matching probe instead marks the block (sizes[i] = kNeedsParse).  (2) lz4_blocks_kernel
+// parses the marked blocks with the full machinery above.  Both produce the serial parser's bytes.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "cw_device.h"
 
@@ -31,6 +41,8 @@ namespace cw {
 namespace {
 
 constexpr uint32_t kTabBytes = (1u << 13) * 2; // 8192 x u16
+constexpr uint32_t kNeedsParse = 0xFFFFFFFFu;  // sizes[] marker: scan kernel -> parse kernel
+constexpr int kScanGroup = 8;                  // probe batches in flight per wavefront in the scan kernel
 constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMFLimit = 12;
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -81,7 +93,155 @@ __device__ __forceinline__ uint32_t put_len(uint8_t *__restrict__ g, uint32_t ex
     return n255 + 1;
 }
 
+
+// wavefront copy global -> global, any alignment: aligned 16 B stores fed by unaligned 16 B loads
+__device__ __forceinline__ void copy_g2g(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t len, uint32_t lane)
+{
+    if (len < 64) {
+        if (lane < len) d[lane] = s[lane];
+        return;
+    }
+    const uint32_t head = (uint32_t)(0 - reinterpret_cast<uintptr_t>(d)) & 15u;
+    if (lane < head) d[lane] = s[lane];
+    d += head; s += head; len -= head;
+    const uint32_t nvec = len >> 4;
+    uint32_t i = lane;
+    for (; i + 7 * 64 < nvec; i += 8 * 64) { // 8 KiB in flight per wavefront
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) __builtin_memcpy(&v[u], s + 16 * (size_t)(i + 64 * u), 16);
+#pragma unroll
+        for (int u = 0; u < 8; u++) *reinterpret_cast<uint4 *>(d + 16 * (size_t)(i + 64 * u)) = v[u];
+    }
+    for (; i < nvec; i += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, s + 16 * (size_t)i, 16);
+        *reinterpret_cast<uint4 *>(d + 16 * (size_t)i) = v;
+    }
+    const uint32_t done = nvec << 4, tail = len - done;
+    if (lane < tail) d[done + lane] = s[done + lane];
+}
+
+__device__ __forceinline__ uint32_t ld32g(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4); // unaligned global_load_dword
+    return v;
+}
+
 } // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Scan kernel: the no-match walk of the serial parser, all probes of a block in flight.
+//
+// A table entry is one 32-bit LDS word  epoch:4 | position:16 | fingerprint:12  inserted with a
+// returning atomic max.  Positions only grow during a walk, so within an epoch "max" is the parser's
+// overwrite, and the returned old word is the entry the parser would have read -- also between lanes of
+// one batch that hit the same slot, PROVIDED the LDS applies same-address atomics of one instruction in
+// ascending lane order.  That order is not architecturally promised, so it is checked rather than
+// assumed: any other order hands some lane a candidate >= its own position, which the serial parser can
+// never see, and such a block is simply marked for the parse kernel.
+// The fingerprint is 12 further bits of the probe value's multiplicative hash: the parser's test
+// read32(candidate) == read32(position) can only hold when the fingerprints agree, so the candidate's
+// bytes are fetched from memory only on a fingerprint hit (~0.2 per incompressible 64 KiB block) instead
+// of 64 random cache lines per batch.  The epoch makes entries of earlier blocks read as "empty"
+// (candidate = position 0, as in the parser's zeroed table) so the table is re-zeroed once per 15 blocks.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
+                uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nbatches)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t limit = n >= 11 ? n - 11 : 0; // forwardIp > mflimitPlusOne ends the walk
+    uint32_t epoch = 15;                         // forces a clean table before the first block
+
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        if (++epoch == 16) { // tags exhausted: start over on a clean table
+            for (uint32_t i = lane; i < (1u << 13) / 4; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
+            epoch = 1;
+        }
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+        const uint32_t tag = epoch << 28;
+        bool hit = false;
+
+        if (nbatches) {
+            const uint32_t v0 = ld32g(g);
+            {   // position 0 (LZ4_putPosition of the first bytes)
+                const uint32_t h0 = v0 * 2654435761u;
+                if (lane == 0) atomicMax(&tab[h0 >> 19], tag | ((h0 >> 7) & 0xFFFu));
+            }
+            uint32_t pos[kScanGroup], v[kScanGroup];
+            bool valid[kScanGroup];
+            auto fetch = [&](uint32_t b0) {
+#pragma unroll
+                for (int j = 0; j < kScanGroup; j++) {
+                    const uint32_t k = 64 * (b0 + j) + lane;
+                    pos[j] = 1 + probe_delta(k);
+                    valid[j] = b0 + j < nbatches && 1 + probe_delta(k + 1) <= limit;
+                    v[j] = valid[j] ? ld32g(g + pos[j]) : 0;
+                }
+            };
+            fetch(0);
+            for (uint32_t b0 = 0; b0 < nbatches; b0 += kScanGroup) {
+                uint32_t cpos[kScanGroup], cv[kScanGroup];
+                bool cvalid[kScanGroup];
+#pragma unroll
+                for (int j = 0; j < kScanGroup; j++) { cpos[j] = pos[j]; cv[j] = v[j]; cvalid[j] = valid[j]; }
+                if (b0 + kScanGroup < nbatches) fetch(b0 + kScanGroup); // next group's loads fly under this group's LDS work
+                bool maybe = false;
+                uint32_t mcand = 0, mv = 0;
+#pragma unroll
+                for (int j = 0; j < kScanGroup; j++) {
+                    if (cvalid[j]) {
+                        const uint32_t h = cv[j] * 2654435761u, fp = (h >> 7) & 0xFFFu;
+                        const uint32_t old = atomicMax(&tab[h >> 19], tag | (cpos[j] << 12) | fp);
+                        if ((old >> 28) == epoch) {
+                            const uint32_t cand = (old >> 12) & 0xFFFFu;
+                            hit |= cand >= cpos[j];
+                            if ((old & 0xFFFu) == fp) {
+                                if (maybe) hit = true; // second one for this lane in this group: let the parser decide
+                                maybe = true; mcand = cand; mv = cv[j];
+                            }
+                        } else {
+                            hit |= cv[j] == v0; // empty slot: the parser's candidate is position 0
+                        }
+                    }
+                }
+                // rare: a fingerprint agreed -- settle it on the candidate's actual bytes
+                if (__ballot(maybe)) {
+                    if (maybe) hit |= ld32g(g + mcand) == mv;
+                }
+                if (__ballot(hit)) break;
+            }
+        }
+        if (__ballot(hit)) {
+            if (lane == 0) sizes[blk] = kNeedsParse;
+            continue;
+        }
+        // no probe matched: the whole block is one literal run
+        uint32_t op = 1;
+        if (n >= 15) {
+            if (lane == 0) out[0] = 15u << 4;
+            op += put_len(out + 1, n - 15, lane);
+        } else if (lane == 0) {
+            out[0] = (uint8_t)(n << 4);
+        }
+        copy_g2g(out + op, g, n, lane);
+        if (lane == 0) sizes[blk] = op + n;
+    }
+}
+
+// number of 64-probe batches of a no-match walk over n bytes (host)
+static uint32_t scan_batches(uint32_t n)
+{
+    if (n < kMFLimit + 1) return 0;
+    const uint32_t limit = n - 11;
+    uint32_t k = 0, p = 1, step = 1, nb = 64; // probe k sits at p; it runs iff the next position <= limit
+    while (p + step <= limit) { p += step; step = nb++ >> 6; k++; }
+    return (k + 63) / 64; // k = number of probes that run
+}
 
 __global__ void __launch_bounds__(64)
 lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
@@ -93,6 +253,7 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
     const uint32_t lane = threadIdx.x;
 
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        if (sizes[blk] != kNeedsParse) continue; // the scan kernel finished this block
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
 
@@ -248,7 +409,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
 {
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536) return hipErrorInvalidValue;
-    const uint32_t lds = (uint32_t)((block_bytes + 15) & ~(size_t)15) + kTabBytes;
+    const uint32_t n = (uint32_t)block_bytes;
+    const uint32_t lds = ((n + 15u) & ~15u) + kTabBytes;
     static bool attr_set = false; // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_blocks_kernel),
@@ -256,11 +418,21 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // one wavefront per workgroup; LDS admits 160 KiB / lds workgroups per CU, so a few thousand
-    // workgroups keep every CU's LDS full while the grid-stride loop walks the rest
-    size_t grid = nblocks < 256 * 10 ? nblocks : 256 * 10;
-    hipLaunchKernelGGL(lz4_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, (uint32_t)block_bytes, src_stride,
-                       nblocks, dst, dst_stride, sizes);
+    // CW_LZ4_MODE=scan stops after the scan kernel (marked blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
+    static const char *mode = getenv("CW_LZ4_MODE");
+    const bool scan_only = mode && strcmp(mode, "scan") == 0;
+    // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
+    const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
+    hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
+                       dst_stride, sizes, scan_batches(n));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || scan_only) return e;
+    // parse: marked blocks only; LDS admits 160 KiB / lds workgroups per CU
+    const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
+    const size_t want = 256 * (per_cu > 8 ? 8 : per_cu);
+    const size_t grid = nblocks < want ? nblocks : want;
+    hipLaunchKernelGGL(lz4_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                       dst_stride, sizes);
     return hipGetLastError();
 }
 

@@ -59,6 +59,7 @@ ms = e0.elapsed_time(e1) / a.iters
 gb = a.nb * a.bs / 1e9
 extra = ""
 if a.comp:
-    extra = f" ratio={a.nb * a.bs / float(sizes.sum().item()):.4f}"
+    marked = int((sizes == -1).sum().item())
+    extra = f" ratio={a.nb * a.bs / float(sizes[sizes != -1].sum().item() + marked * a.bs):.4f} marked={marked}"
 print(f"lib={os.path.basename(cw.lib_path())} alg={a.alg} comp={a.comp or '-'} bs={a.bs} nb={a.nb} data={a.data}: "
       f"{ms:.3f} ms/pass  {gb / (ms / 1e3):.1f} GB/s{extra}", flush=True)
