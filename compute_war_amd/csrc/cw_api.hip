@@ -72,6 +72,32 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// fork/join helper for cw_dev_hash_and_compress: the codec runs on a side stream beside the hash
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+    int open()
+    {
+        const int dev = g_device.load();
+        if (side && device == dev) return CW_OK;
+        HIP_TRY(hipSetDevice(dev));
+        int least = 0, greatest = 0; // the hash is the long, ALU-bound kernel: it yields dispatch slots to the codec
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
+        HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        device = dev;
+        return CW_OK;
+    }
+    ~SideStream()
+    {
+        if (!side) return;
+        (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(side);
+    }
+};
+thread_local SideStream t_side;
+
 struct ThreadCtx {
     hipStream_t stream = nullptr;
     DevBuf src, dst, dig, sizes;
@@ -230,13 +256,29 @@ int cw_dev_compress(int comp_alg, const void *d_src, size_t block_bytes, size_t 
 int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size_t block_bytes, size_t src_stride,
                              size_t nblocks, void *d_digests, void *d_dst, size_t dst_stride, uint32_t *d_sizes, void *stream)
 {
-    // ProcessBlock order (:243-257): compress, then hash.  Both kernels go to the same stream; they
-    // read the same input and write disjoint outputs.
-    int rc = CW_OK;
-    if (comp_alg != CW_COMP_NONE)
+    // ProcessBlock (:243-257) compresses, then hashes; the two only share their read-only input, so they run
+    // side by side: the codec (latency/memory bound, few issue slots, persistent grid) goes first on the
+    // caller's stream so its workgroups are resident before the hash (pure integer VALU, one long-lived
+    // wavefront per 64 blocks) fills the rest of every CU from a low-priority side stream; the side stream
+    // is joined before this call's work counts as done.
+    if (comp_alg == CW_COMP_NONE) return cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, stream);
+    if (hash_alg == CW_HASH_NONE)
+        return cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    static const char *serial = getenv("CW_SERIAL"); // CW_SERIAL=1: both kernels on the caller's stream (profiling knob)
+    if (serial && serial[0] == '1') {
         rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
-    if (rc == CW_OK && hash_alg != CW_HASH_NONE)
-        rc = cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, stream);
+        return rc == CW_OK ? cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, stream) : rc;
+    }
+    if ((rc = t_side.open()) != CW_OK) return rc;
+    hipStream_t main_s = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(t_side.fork, main_s));
+    HIP_TRY(hipStreamWaitEvent(t_side.side, t_side.fork, 0));
+    rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
+    if (rc == CW_OK) rc = cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, t_side.side);
+    HIP_TRY(hipEventRecord(t_side.join, t_side.side));
+    HIP_TRY(hipStreamWaitEvent(main_s, t_side.join, 0));
     return rc;
 }
 

@@ -153,6 +153,8 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
     const uint32_t lane = threadIdx.x;
+    // latency-bound wavefront that shares its SIMD with ALU-bound hash wavefronts: issue ahead of them
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t limit = n >= 11 ? n - 11 : 0; // forwardIp > mflimitPlusOne ends the walk
     uint32_t epoch = 15;                         // forces a clean table before the first block
 
