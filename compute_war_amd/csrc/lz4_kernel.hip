@@ -34,6 +34,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "cw_device.h"
 
 namespace cw {
@@ -42,7 +45,7 @@ namespace {
 
 constexpr uint32_t kTabBytes = (1u << 13) * 2; // 8192 x u16
 constexpr uint32_t kNeedsParse = 0xFFFFFFFFu;  // sizes[] marker: scan kernel -> parse kernel
-constexpr int kScanGroup = 8;                  // probe batches in flight per wavefront in the scan kernel
+constexpr int kScanGroup = 16;                 // probe batches in flight per wavefront in the generic scan kernel
 constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMFLimit = 12;
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -106,12 +109,12 @@ __device__ __forceinline__ void copy_g2g(uint8_t *__restrict__ d, const uint8_t 
     d += head; s += head; len -= head;
     const uint32_t nvec = len >> 4;
     uint32_t i = lane;
-    for (; i + 7 * 64 < nvec; i += 8 * 64) { // 8 KiB in flight per wavefront
-        uint4 v[8];
+    for (; i + 15 * 64 < nvec; i += 16 * 64) { // 16 KiB in flight per wavefront
+        uint4 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) __builtin_memcpy(&v[u], s + 16 * (size_t)(i + 64 * u), 16);
+        for (int u = 0; u < 16; u++) __builtin_memcpy(&v[u], s + 16 * (size_t)(i + 64 * u), 16);
 #pragma unroll
-        for (int u = 0; u < 8; u++) *reinterpret_cast<uint4 *>(d + 16 * (size_t)(i + 64 * u)) = v[u];
+        for (int u = 0; u < 16; u++) *reinterpret_cast<uint4 *>(d + 16 * (size_t)(i + 64 * u)) = v[u];
     }
     for (; i < nvec; i += 64) {
         uint4 v;
@@ -132,7 +135,7 @@ __device__ __forceinline__ uint32_t ld32g(const uint8_t *p)
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------
-// Scan kernel: the no-match walk of the serial parser, all probes of a block in flight.
+// Scan kernels: the no-match walk of the serial parser, all probes of a block in flight.
 //
 // A table entry is one 32-bit LDS word  epoch:4 | position:16 | fingerprint:12  inserted with a
 // returning atomic max.  Positions only grow during a walk, so within an epoch "max" is the parser's
@@ -140,86 +143,109 @@ __device__ __forceinline__ uint32_t ld32g(const uint8_t *p)
 // one batch that hit the same slot, PROVIDED the LDS applies same-address atomics of one instruction in
 // ascending lane order.  That order is not architecturally promised, so it is checked rather than
 // assumed: any other order hands some lane a candidate >= its own position, which the serial parser can
-// never see, and such a block is simply marked for the parse kernel.
+// never see, and such a block is simply queued for the parse kernel.
 // The fingerprint is 12 further bits of the probe value's multiplicative hash: the parser's test
 // read32(candidate) == read32(position) can only hold when the fingerprints agree, so the candidate's
 // bytes are fetched from memory only on a fingerprint hit (~0.2 per incompressible 64 KiB block) instead
 // of 64 random cache lines per batch.  The epoch makes entries of earlier blocks read as "empty"
 // (candidate = position 0, as in the parser's zeroed table) so the table is re-zeroed once per 15 blocks.
 // ---------------------------------------------------------------------------------------------------
+struct ScanState {
+    bool hit = false, maybe = false;
+    uint32_t mcand = 0, mv = 0;
+};
+
+// one probe per active lane: insert (pos, v) and test it the way the parser would
+__device__ __forceinline__ void scan_probe(uint32_t *tab, uint32_t tag, uint32_t epoch, uint32_t v0, uint32_t pos, uint32_t v,
+                                           bool active, ScanState &st)
+{
+    if (!active) return;
+    const uint32_t h = v * 2654435761u, fp = (h >> 7) & 0xFFFu;
+    const uint32_t old = atomicMax(&tab[h >> 19], tag | (pos << 12) | fp);
+    if ((old >> 28) == epoch) {
+        const uint32_t cand = (old >> 12) & 0xFFFFu;
+        st.hit |= cand >= pos;
+        if ((old & 0xFFFu) == fp) {
+            if (st.maybe) st.hit = true; // a second one for this lane before settling: let the parser decide
+            st.maybe = true; st.mcand = cand; st.mv = v;
+        }
+    } else {
+        st.hit |= v == v0; // empty slot: the parser's candidate is position 0
+    }
+}
+
+// rare: a fingerprint agreed -- settle it on the candidate's actual bytes; returns the wave-wide verdict
+__device__ __forceinline__ bool scan_settle(const uint8_t *g, ScanState &st)
+{
+    if (__ballot(st.maybe)) {
+        if (st.maybe) st.hit |= ld32g(g + st.mcand) == st.mv;
+        st.maybe = false;
+    }
+    return __ballot(st.hit) != 0;
+}
+
+__device__ __forceinline__ void scan_begin_block(uint32_t *tab, uint32_t &epoch, uint32_t lane)
+{
+    if (++epoch == 16) { // tags exhausted: start over on a clean table
+        for (uint32_t i = lane; i < (1u << 13) / 4; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
+        epoch = 1;
+    }
+}
+
+__device__ __forceinline__ void scan_mark(uint32_t *sizes, size_t blk, uint32_t *queue, uint32_t *counters, uint32_t lane)
+{
+    if (lane == 0) {
+        sizes[blk] = kNeedsParse;
+        queue[atomicAdd(&counters[1], 1u)] = (uint32_t)blk; // counters[1] = queue tail
+    }
+}
+
+// Probes gather their 4 bytes from global memory (kScanGroup batches in flight per wavefront); a block in which
+// none matched is written as one literal run: header bytes here, and the literal bytes either here too
+// (COPY, one global->global copy) or -- when a hash kernel walks the same blocks anyway -- by that kernel,
+// which already holds every byte of every block in registers (skein_lines_kernel<.., RAW>).
+template <bool COPY>
 __global__ void __launch_bounds__(64)
 lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
-                uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nbatches)
+                        uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nprobes,
+                        uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
     const uint32_t lane = threadIdx.x;
-    // latency-bound wavefront that shares its SIMD with ALU-bound hash wavefronts: issue ahead of them
-    __builtin_amdgcn_s_setprio(3);
-    const uint32_t limit = n >= 11 ? n - 11 : 0; // forwardIp > mflimitPlusOne ends the walk
-    uint32_t epoch = 15;                         // forces a clean table before the first block
+    __builtin_amdgcn_s_setprio(3); // latency-bound wavefront next to ALU-bound hash wavefronts: issue ahead of them
+    uint32_t epoch = 15;           // forces a clean table before the first block
 
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        if (++epoch == 16) { // tags exhausted: start over on a clean table
-            for (uint32_t i = lane; i < (1u << 13) / 4; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
-            epoch = 1;
-        }
+        scan_begin_block(tab, epoch, lane);
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
         const uint32_t tag = epoch << 28;
-        bool hit = false;
+        ScanState st;
+        bool marked = false;
 
-        if (nbatches) {
+        if (nprobes) {
             const uint32_t v0 = ld32g(g);
             {   // position 0 (LZ4_putPosition of the first bytes)
                 const uint32_t h0 = v0 * 2654435761u;
                 if (lane == 0) atomicMax(&tab[h0 >> 19], tag | ((h0 >> 7) & 0xFFFu));
             }
-            uint32_t pos[kScanGroup], v[kScanGroup];
-            bool valid[kScanGroup];
-            auto fetch = [&](uint32_t b0) {
+            for (uint32_t k0 = 0; k0 < nprobes && !marked; k0 += 64 * kScanGroup) {
+                uint32_t pos[kScanGroup], v[kScanGroup];
+                bool act[kScanGroup];
 #pragma unroll
                 for (int j = 0; j < kScanGroup; j++) {
-                    const uint32_t k = 64 * (b0 + j) + lane;
+                    const uint32_t k = k0 + 64 * j + lane;
                     pos[j] = 1 + probe_delta(k);
-                    valid[j] = b0 + j < nbatches && 1 + probe_delta(k + 1) <= limit;
-                    v[j] = valid[j] ? ld32g(g + pos[j]) : 0;
+                    act[j] = k < nprobes;
+                    v[j] = act[j] ? ld32g(g + pos[j]) : 0;
                 }
-            };
-            fetch(0);
-            for (uint32_t b0 = 0; b0 < nbatches; b0 += kScanGroup) {
-                uint32_t cpos[kScanGroup], cv[kScanGroup];
-                bool cvalid[kScanGroup];
 #pragma unroll
-                for (int j = 0; j < kScanGroup; j++) { cpos[j] = pos[j]; cv[j] = v[j]; cvalid[j] = valid[j]; }
-                if (b0 + kScanGroup < nbatches) fetch(b0 + kScanGroup); // next group's loads fly under this group's LDS work
-                bool maybe = false;
-                uint32_t mcand = 0, mv = 0;
-#pragma unroll
-                for (int j = 0; j < kScanGroup; j++) {
-                    if (cvalid[j]) {
-                        const uint32_t h = cv[j] * 2654435761u, fp = (h >> 7) & 0xFFFu;
-                        const uint32_t old = atomicMax(&tab[h >> 19], tag | (cpos[j] << 12) | fp);
-                        if ((old >> 28) == epoch) {
-                            const uint32_t cand = (old >> 12) & 0xFFFFu;
-                            hit |= cand >= cpos[j];
-                            if ((old & 0xFFFu) == fp) {
-                                if (maybe) hit = true; // second one for this lane in this group: let the parser decide
-                                maybe = true; mcand = cand; mv = cv[j];
-                            }
-                        } else {
-                            hit |= cv[j] == v0; // empty slot: the parser's candidate is position 0
-                        }
-                    }
-                }
-                // rare: a fingerprint agreed -- settle it on the candidate's actual bytes
-                if (__ballot(maybe)) {
-                    if (maybe) hit |= ld32g(g + mcand) == mv;
-                }
-                if (__ballot(hit)) break;
+                for (int j = 0; j < kScanGroup; j++) scan_probe(tab, tag, epoch, v0, pos[j], v[j], act[j], st);
+                marked = scan_settle(g, st);
             }
         }
-        if (__ballot(hit)) {
-            if (lane == 0) sizes[blk] = kNeedsParse;
+        if (marked) {
+            scan_mark(sizes, blk, queue, counters, lane);
             continue;
         }
         // no probe matched: the whole block is one literal run
@@ -230,32 +256,44 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
         } else if (lane == 0) {
             out[0] = (uint8_t)(n << 4);
         }
-        copy_g2g(out + op, g, n, lane);
+        if (COPY) copy_g2g(out + op, g, n, lane);
         if (lane == 0) sizes[blk] = op + n;
     }
 }
 
-// number of 64-probe batches of a no-match walk over n bytes (host)
-static uint32_t scan_batches(uint32_t n)
+// number of probes of a no-match walk over n bytes (host)
+static uint32_t scan_probes(uint32_t n)
 {
     if (n < kMFLimit + 1) return 0;
     const uint32_t limit = n - 11;
     uint32_t k = 0, p = 1, step = 1, nb = 64; // probe k sits at p; it runs iff the next position <= limit
     while (p + step <= limit) { p += step; step = nb++ >> 6; k++; }
-    return (k + 63) / 64; // k = number of probes that run
+    return k;
 }
 
+// Parse kernel: the full greedy parse of the blocks the scan queued (queue[0 .. counters[1]); counters[0] is the
+// shared head the workgroups pull from, so a handful of queued blocks spreads over as many workgroups).
 __global__ void __launch_bounds__(64)
 lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
-                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes)
+                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes,
+                  const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *in = smem;                                                  // the block, n bytes
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem + ((n + 15u) & ~15u)); // position table
     const uint32_t lane = threadIdx.x;
 
-    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        if (sizes[blk] != kNeedsParse) continue; // the scan kernel finished this block
+    const uint32_t qcount = counters[1];
+    volatile uint32_t *mailbox = reinterpret_cast<volatile uint32_t *>(tab); // table memory, before it is cleared
+    for (uint32_t guard = 0; guard <= qcount; guard++) { // each pull advances the shared head; never more than qcount+1 pulls
+        // one lane pulls the next queue index and hands it to the wavefront through LDS (a divergent branch
+        // feeding readfirstlane directly was mis-structured by hipcc into a loop that never re-pulled)
+        __syncthreads(); // previous block's LDS readers are done
+        if (lane == 0) *mailbox = atomicAdd(&counters[0], 1u);
+        __syncthreads();
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(*mailbox);
+        if (qi >= qcount) break;
+        const size_t blk = queue[qi];
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
 
@@ -406,11 +444,34 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
     }
 }
 
+// per-stream workspace: counters[2] (queue head, tail) followed by the queue of block indices
+namespace {
+struct Workspace { uint32_t *p = nullptr; size_t cap = 0; };
+std::mutex ws_lock;
+std::unordered_map<hipStream_t, Workspace> ws_map;
+
+hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out)
+{
+    std::lock_guard<std::mutex> g(ws_lock);
+    Workspace &w = ws_map[stream];
+    if (w.cap < nblocks) { // only ever on the first (or a larger) call on this stream
+        if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
+        w.p = nullptr; w.cap = 0;
+        size_t cap = nblocks < 4096 ? 4096 : nblocks;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.p), (cap + 4) * sizeof(uint32_t));
+        if (e != hipSuccess) return e;
+        w.cap = cap;
+    }
+    *out = w.p;
+    return hipSuccess;
+}
+} // namespace
+
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
-                      size_t dst_stride, uint32_t *sizes, hipStream_t stream)
+                      size_t dst_stride, uint32_t *sizes, hipStream_t stream, int phase)
 {
     if (nblocks == 0) return hipSuccess;
-    if (block_bytes == 0 || block_bytes > 65536) return hipErrorInvalidValue;
+    if (block_bytes == 0 || block_bytes > 65536 || nblocks > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
     const uint32_t lds = ((n + 15u) & ~15u) + kTabBytes;
     static bool attr_set = false; // benign race: idempotent
@@ -420,21 +481,32 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // CW_LZ4_MODE=scan stops after the scan kernel (marked blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
+    uint32_t *ws = nullptr;
+    hipError_t e = get_workspace(stream, nblocks, &ws);
+    if (e != hipSuccess) return e;
+    uint32_t *counters = ws, *queue = ws + 4;
+
+    if (phase != kLz4ParseOnly) {
+        if ((e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
+        const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
+        if (phase == kLz4ProbeOnly)
+            hipLaunchKernelGGL(lz4_scan_kernel<false>, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride,
+                               nblocks, dst, dst_stride, sizes, scan_probes(n), queue, counters);
+        else
+            hipLaunchKernelGGL(lz4_scan_kernel<true>, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride,
+                               nblocks, dst, dst_stride, sizes, scan_probes(n), queue, counters);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    // CW_LZ4_MODE=scan stops after the scan kernel (queued blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
     static const char *mode = getenv("CW_LZ4_MODE");
-    const bool scan_only = mode && strcmp(mode, "scan") == 0;
-    // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
-    const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
-    hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes, scan_batches(n));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || scan_only) return e;
-    // parse: marked blocks only; LDS admits 160 KiB / lds workgroups per CU
+    if (phase == kLz4ProbeOnly || (mode && strcmp(mode, "scan") == 0)) return hipSuccess;
+    // parse: queued blocks only; LDS admits 160 KiB / lds workgroups per CU
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
     const size_t want = 256 * (per_cu > 8 ? 8 : per_cu);
     const size_t grid = nblocks < want ? nblocks : want;
     hipLaunchKernelGGL(lz4_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes);
+                       dst_stride, sizes, queue, counters);
     return hipGetLastError();
 }
 

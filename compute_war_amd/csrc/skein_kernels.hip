@@ -272,10 +272,14 @@ skein_blocks_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t 
 // (rocprofv3 FETCH_SIZE, profiles/) -- and the NEXT line is requested before the current line's 144 rounds
 // start, which hides HBM latency under ~5 us of integer work per wavefront.
 // ---------------------------------------------------------------------------------------------------
-template <int NW, bool ALIGNED16>
+// RAW: the lane also stores its block's bytes, as they pass through its registers, at raw.dst + i*raw.stride +
+// raw.hdr -- the literal run of the block in the LZ4 output slot, should the codec's scan find the block
+// incompressible (the scan writes the run's header bytes and the size; a block it queues for the parser is
+// simply overwritten later).  This saves the codec a second pass over every incompressible block.
+template <int NW, bool ALIGNED16, bool RAW>
 __global__ void __launch_bounds__(CW_SKEIN_THREADS)
 skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t src_stride, size_t nblocks,
-                   SkeinIV iv, uint8_t *__restrict__ digests, unsigned digest_bytes)
+                   SkeinIV iv, uint8_t *__restrict__ digests, unsigned digest_bytes, RawCopy raw)
 {
     constexpr unsigned BB = NW * 8, SPL = 128 / BB; // steps per 128-byte line
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,9 +309,25 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     };
     fetch_line(cur, 0);
 
+    uint8_t *rawp = RAW ? raw.dst + gid * raw.stride + raw.hdr : nullptr;
+
 #pragma unroll 1
     for (size_t line = 0; line * SPL < total; line++) {
         fetch_line(nxt, line + 1);
+        if (RAW) {
+#pragma unroll
+            for (unsigned j = 0; j < SPL; j++) {
+                const size_t s = line * SPL + j;
+                if (s < nmsg) {
+#pragma unroll
+                    for (int k = 0; k < NW / 2; k++) {
+                        const uint4 v = make_uint4((uint32_t)cur[j][2 * k], (uint32_t)(cur[j][2 * k] >> 32),
+                                                   (uint32_t)cur[j][2 * k + 1], (uint32_t)(cur[j][2 * k + 1] >> 32));
+                        __builtin_memcpy(rawp + s * BB + 16 * k, &v, 16); // unaligned global_store_dwordx4
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (unsigned j = 0; j < SPL; j++) {
             const size_t s = line * SPL + j;
@@ -345,7 +365,7 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 
 template <int NW>
 static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw)
 {
     if (nblocks == 0) return hipSuccess;
     if ((digest_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(digests) & 15)) return hipErrorInvalidValue;
@@ -354,27 +374,34 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
     const bool ragged = block_bytes == 0 || (block_bytes % (NW * 8)) != 0;
 #define CW_LAUNCH(A, R) hipLaunchKernelGGL((skein_blocks_kernel<NW, A, R>), grid, block, 0, stream, \
                                            src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
-#define CW_LAUNCH_LINES(A) hipLaunchKernelGGL((skein_lines_kernel<NW, A>), grid, block, 0, stream, \
-                                              src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
-    if (aligned && !ragged) CW_LAUNCH_LINES(true);
+#define CW_LAUNCH_LINES(A, R) hipLaunchKernelGGL((skein_lines_kernel<NW, A, R>), grid, block, 0, stream, \
+                                                 src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, raw)
+    if (raw.dst && !(aligned && !ragged)) return hipErrorInvalidValue; // see skein_can_rawcopy()
+    if (aligned && !ragged && raw.dst) CW_LAUNCH_LINES(true, true);
+    else if (aligned && !ragged) CW_LAUNCH_LINES(true, false);
     else if (aligned) CW_LAUNCH(true, true);
-    else if (!ragged) CW_LAUNCH_LINES(false);
+    else if (!ragged) CW_LAUNCH_LINES(false, false);
     else CW_LAUNCH(false, true);
 #undef CW_LAUNCH
 #undef CW_LAUNCH_LINES
     return hipGetLastError();
 }
 
-hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+bool skein_can_rawcopy(const uint8_t *src, size_t block_bytes, size_t src_stride, int nw)
 {
-    return launch_skein<8>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream);
+    return block_bytes != 0 && block_bytes % ((size_t)nw * 8) == 0 && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
+}
+
+hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw)
+{
+    return launch_skein<8>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream, raw);
 }
 
 hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw)
 {
-    return launch_skein<4>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream);
+    return launch_skein<4>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream, raw);
 }
 
 // ---- host-side config-block UBI (Skein_*_Init's "no precomputed IV" path, skein.c:245-259) ----

@@ -142,6 +142,18 @@ def dev_sum_sizes(d_sizes: int, nblocks: int, raw_bytes: int, d_totals: int, str
     check(lib().cw_dev_sum_sizes(d_sizes, nblocks, raw_bytes, d_totals, stream))
 
 
+def profile_enable(on: bool = True) -> None:
+    lib().cw_profile_enable(1 if on else 0)
+
+
+def profile_read(reset: bool = True) -> dict:
+    """{'codec': (ms_sum, launches), 'hash': ..., 'parse': ...} from the library's own HIP events."""
+    ms = (C.c_double * 3)()
+    cnt = (C.c_uint * 3)()
+    check(lib().cw_profile_read(ms, cnt, 1 if reset else 0))
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(("codec", "hash", "parse"))}
+
+
 # ---- HashOffload ------------------------------------------------------------------------------------
 class HashOffload:
     """HashOffload.h:13-64: Reset(data, results, onComplete) -> Enqueue() -> Start() -> Complete()."""

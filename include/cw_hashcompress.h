@@ -114,6 +114,13 @@ int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_
 int cw_dev_sum_sizes(const uint32_t *d_sizes, size_t nblocks, uint32_t raw_bytes, uint64_t *d_totals,
                      void *stream);
 
+/* ---- kernel timing (the reference times with std::chrono around its calls, hash.cpp:11-18, HashAndCompress.cpp:397-406;
+ *      device work is asynchronous, so the library brackets its own launches with HIP events on the stream each
+ *      kernel is launched on).  Per calling thread.  Kinds: [0] codec scan (+parse when not split), [1] hash,
+ *      [2] codec parse of the queued blocks (split path of cw_dev_hash_and_compress).                              */
+void cw_profile_enable(int on);
+int  cw_profile_read(double ms_sum[3], unsigned count[3], int reset);   /* synchronises on the recorded events */
+
 /* ---- HashOffload (HashOffload.h:13-64): batch object + the offload thread that drains it -------
  * Lifecycle  hInit --Enqueue--> hQueued --Start--> hOffloaded --Complete--> hComplete.
  * Start() = "xfer data, load kernel" (:26-31): async H2D + hash kernel + async D2H on the object's stream.
