@@ -161,6 +161,75 @@ def test_slot_do_compression_lz4(cw, oracle):
     assert cw.do_compression("lz4", b) == oracle.lz4_compress(b)
 
 
+# ---------------------------------------------------------------- LZF
+def _check_lzf(cw, oracle, data: bytes, bs: int):
+    sizes, payload = cw.compress_blocks("lzf", data, bs)
+    for i in range(len(data) // bs):
+        want = oracle.lzf_compress(data[i * bs:(i + 1) * bs])   # b"" = did not fit l-1 (returns 0)
+        got = payload[i, :sizes[i]].tobytes()
+        assert sizes[i] == len(want) and got == want, (bs, i, int(sizes[i]), len(want))
+    return sizes
+
+
+@pytest.mark.parametrize("bs", [4096, 65536])
+def test_lzf_canterbury_bit_exact(cw, oracle, bs):
+    tin = tout = 0
+    for name in corpus_names():
+        data = corpus_file(name)
+        whole = len(data) // 65536 * 65536
+        if not whole:
+            continue
+        sizes = _check_lzf(cw, oracle, data[:whole], bs)
+        tin += whole
+        tout += int(np.where(sizes == 0, bs, sizes).sum())
+    want = next(r for r in load_golden("survey_anchors.json")["corpus_ratios"]
+                if r["corpus"] == "canterbury" and r["block"] == bs)
+    assert round(tin / tout, 4) == want["lzf"]
+
+
+def test_lzf_survey_anchors(cw):
+    for a in load_golden("survey_anchors.json")["anchors"]:
+        d = anchor_input(a["input"], a["n"])
+        sizes, payload = cw.compress_blocks("lzf", d, a["n"])
+        assert sizes[0] == a["lzf"]
+        if "lzf_sha256" in a:
+            assert hashlib.sha256(payload[0, :sizes[0]].tobytes()).hexdigest() == a["lzf_sha256"]
+
+
+def test_lzf_edge_cases(cw, oracle):
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 3, 4, 5, 16, 17, 18, 19, 20, 21, 22, 31, 32, 33, 34, 35, 63, 64, 65, 66, 67, 255, 263, 264, 265, 266,
+              267, 268, 300, 1000, 4095, 4097, 16384, 16385, 65535, 65536):
+        for alphabet in (1, 2, 3, 16, 256):
+            count = 3 if n > 4096 else 40
+            data = rng.integers(0, alphabet, n * count, dtype=np.uint8).tobytes()
+            _check_lzf(cw, oracle, data, n)
+    for period in (1, 2, 3, 4, 7, 8, 255, 256, 263, 264, 265, 8191, 8192, 8193):
+        base = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+        for n in (4096, 65536):
+            _check_lzf(cw, oracle, (base * (70000 // period + 1))[:n], n)
+
+
+def test_lzf_random_blocks_do_not_fit(cw, oracle):
+    data = oracle.gen_random_blocks(0xC0FFEE, 77, 4, 65536).tobytes()
+    sizes = _check_lzf(cw, oracle, data, 65536)
+    assert all(int(x) == 0 for x in sizes)    # lzf_compress(.., l-1) returns 0 on incompressible data
+    assert cw.do_compression("lzf", data[:4096]) == b""
+    b = corpus_file("alice29.txt")[:4096]
+    assert cw.do_compression("lzf", b) == oracle.lzf_compress(b)
+
+
+def test_sha256_lzf_pipeline(cw, oracle):
+    """The reference's hc_shlzf configuration (run_tests:20): sha256mb + lzf, read-blocks 8, 4 KiB blocks."""
+    data = corpus_file("lcet10.txt")[:64 * 4096]
+    dig, sizes, payload = cw.hash_and_compress_blocks("sha256mb", "lzf", data, 4096)
+    for i in range(64):
+        b = data[i * 4096:(i + 1) * 4096]
+        assert dig[i].tobytes() == hashlib.sha256(b).digest()
+        want = oracle.lzf_compress(b)
+        assert sizes[i] == len(want) and payload[i, :sizes[i]].tobytes() == want
+
+
 # ---------------------------------------------------------------- device API, fused, offload
 def test_dev_hash_and_compress_matches_oracle(cw, oracle):
     import torch
