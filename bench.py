@@ -72,18 +72,19 @@ def cpu_baseline(args, target_s: float):
     bs = args.block_bytes
     h = {"skein512": O.HASH_SKEIN512, "skein": O.HASH_SKEIN256_128, "sha256mb": O.HASH_SHA256}[args.hash]
     c = {"lz4": O.COMP_LZ4, "lzf": O.COMP_LZF}[args.comp]
-    # calibrate on a few blocks per thread, then size the sample for ~target_s seconds
-    nb = 4 * threads
+    # bounded sample: a fixed 2 GiB (or smaller) synthetic stream, passed over repeatedly until ~target_s seconds
+    nb = max(threads, min((2 << 30) // bs, 1 << 20))
     data = O.gen_random_blocks(SEED, 0, nb, bs)
-    secs, *_ = O.hash_and_compress(data, bs, h, c, threads, want_payload=False)
-    rate = nb / max(secs, 1e-6)
-    nb = int(max(threads, min(rate * target_s, (8 << 30) // bs)))
-    data = O.gen_random_blocks(SEED, 0, nb, bs)
-    secs, *_ = O.hash_and_compress(data, bs, h, c, threads, want_payload=False)
+    secs, passes = 0.0, 0
+    while secs < target_s and passes < 1000:
+        t, *_ = O.hash_and_compress(data, bs, h, c, threads, want_payload=False)
+        secs += t
+        passes += 1
+    nb *= passes
     return {
         "value": round(nb * bs / secs / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-        "sample": f"{nb} x {bs} B synthetic random blocks ({nb * bs / 2**20:.0f} MiB), {args.hash}+{args.comp}, "
-                  f"oracle worker loop with {threads} threads, {secs:.1f} s",
+        "sample": f"{passes} passes over {nb // passes} x {bs} B synthetic random blocks ({nb // passes * bs / 2**20:.0f} MiB), "
+                  f"{args.hash}+{args.comp}, oracle worker loop with {threads} threads, {secs:.1f} s",
     }
 
 
