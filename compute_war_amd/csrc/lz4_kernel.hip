@@ -212,7 +212,7 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
     const uint32_t lane = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3); // latency-bound wavefront next to ALU-bound hash wavefronts: issue ahead of them
+    __builtin_amdgcn_s_setprio(3); // latency-bound wavefront next to ALU-bound hash wavefronts
     uint32_t epoch = 15;           // forces a clean table before the first block
 
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {

@@ -48,6 +48,10 @@ static __device__ __forceinline__ uint64_t rotl(uint64_t x)
 #ifndef CW_ADD64_PAIR
 #define CW_ADD64_PAIR 0
 #endif
+// message prefetch distance of the line kernel: 0 = one 128-byte line ahead, 1 = two lines ahead (+32 VGPRs)
+#ifndef CW_SKEIN_PREFETCH2
+#define CW_SKEIN_PREFETCH2 0
+#endif
 static __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b)
 {
 #if CW_ADD64_PAIR
@@ -295,6 +299,9 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     uint64_t t0 = 0, t1 = T1_FIRST | T1_MSG;
 
     uint64_t cur[SPL][NW], nxt[SPL][NW];
+#if CW_SKEIN_PREFETCH2
+    uint64_t nx2[SPL][NW];
+#endif
     auto fetch_line = [&](uint64_t (&dst)[SPL][NW], size_t line) {
 #pragma unroll
         for (unsigned j = 0; j < SPL; j++) {
@@ -348,7 +355,12 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 #pragma unroll
         for (unsigned j = 0; j < SPL; j++)
 #pragma unroll
-            for (int k = 0; k < NW; k++) cur[j][k] = nxt[j][k];
+            for (int k = 0; k < NW; k++) {
+                cur[j][k] = nxt[j][k];
+#if CW_SKEIN_PREFETCH2
+                nxt[j][k] = nx2[j][k];
+#endif
+            }
     }
 
     uint8_t *out = digests + gid * digest_bytes;

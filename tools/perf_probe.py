@@ -49,6 +49,7 @@ def run():
 
 run()
 torch.cuda.synchronize()
+cw.profile_enable(True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.iters):
@@ -60,6 +61,9 @@ gb = a.nb * a.bs / 1e9
 extra = ""
 if a.comp:
     marked = int((sizes == -1).sum().item())
-    extra = f" ratio={a.nb * a.bs / float(sizes[sizes != -1].sum().item() + marked * a.bs):.4f} marked={marked}"
+    tot = float(sizes[sizes != -1].sum().item() + marked * a.bs)
+    extra = f" ratio={a.nb * a.bs / max(tot, 1.0):.4f} marked={marked}"
+prof = cw.profile_read()
+extra += " | kernel ms: " + ", ".join(f"{k}={v[0] / max(v[1], 1):.2f}" for k, v in prof.items() if v[1])
 print(f"lib={os.path.basename(cw.lib_path())} alg={a.alg} comp={a.comp or '-'} bs={a.bs} nb={a.nb} data={a.data}: "
       f"{ms:.3f} ms/pass  {gb / (ms / 1e3):.1f} GB/s{extra}", flush=True)
