@@ -8,8 +8,8 @@
 // those written down in SURVEY.md 8(a) row A5 and restated on the CPU in oracle/lz4_oracle.c.
 //
 // Mapping to the machine.  The parse is a serial greedy walk over one mutable hash table, so the unit
-// of parallelism is the block: a 64-lane wavefront owns one block, holds it and its 8192 x u16 table
-// in LDS (64 KiB + 16 KiB = half a CU's LDS), and uses its lanes for the parts that are parallel
+// of parallelism is the block: a 64-lane wavefront owns one block, holds its 8192 x u16 table (and, for
+// blocks up to 16 KiB, the block itself) in LDS, and uses its lanes for the parts that are parallel
 // inside a block:
 //   * the search loop: while no match is found the positions the serial parser will probe do not
 //     depend on the table (only the skip schedule), so lane j speculatively runs probe k0+j; a
@@ -44,6 +44,7 @@ namespace cw {
 namespace {
 
 constexpr uint32_t kTabBytes = (1u << 13) * 2; // 8192 x u16
+constexpr uint32_t kStageMax = 16384;          // parse kernel: blocks up to this size are staged in LDS
 constexpr uint32_t kNeedsParse = 0xFFFFFFFFu;  // sizes[] marker: scan kernel -> parse kernel
 constexpr int kScanGroup = 16;                 // probe batches in flight per wavefront in the generic scan kernel
 constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMFLimit = 12;
@@ -276,11 +277,15 @@ static uint32_t scan_probes(uint32_t n)
 __global__ void __launch_bounds__(64)
 lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
                   uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes,
-                  const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
+                  const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t stage)
 {
+    // LDS: the 16 KiB position table, then (stage != 0) the block itself.  Small blocks are staged: every read of
+    // the parse is then an LDS read.  Large blocks are read through L1/L2 instead: with only the table in LDS ten
+    // blocks fit a CU instead of two, and the parse -- one wavefront per block, bound by its own instruction
+    // issue and dependent round trips -- gains more from the extra wavefronts than it loses to the longer reads.
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *in = smem;                                                  // the block, n bytes
-    uint16_t *tab = reinterpret_cast<uint16_t *>(smem + ((n + 15u) & ~15u)); // position table
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+    uint8_t *lds_in = smem + kTabBytes;
     const uint32_t lane = threadIdx.x;
 
     const uint32_t qcount = counters[1];
@@ -299,13 +304,17 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
 
         // ---- stage the block into LDS (coalesced 16 B per lane) and clear the table ----
         __syncthreads(); // previous block's readers are done
-        if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
-            const uint4 *g4 = reinterpret_cast<const uint4 *>(g);
-            const uint32_t nvec = n >> 4;
-            for (uint32_t i = lane; i < nvec; i += 64) reinterpret_cast<uint4 *>(in)[i] = g4[i];
-            for (uint32_t i = (nvec << 4) + lane; i < n; i += 64) in[i] = g[i];
-        } else {
-            for (uint32_t i = lane; i < n; i += 64) in[i] = g[i];
+        const uint8_t *in = g;
+        if (stage) {
+            if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+                const uint4 *g4 = reinterpret_cast<const uint4 *>(g);
+                const uint32_t nvec = n >> 4;
+                for (uint32_t i = lane; i < nvec; i += 64) reinterpret_cast<uint4 *>(lds_in)[i] = g4[i];
+                for (uint32_t i = (nvec << 4) + lane; i < n; i += 64) lds_in[i] = g[i];
+            } else {
+                for (uint32_t i = lane; i < n; i += 64) lds_in[i] = g[i];
+            }
+            in = lds_in;
         }
         for (uint32_t i = lane; i < kTabBytes / 16; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
@@ -314,115 +323,124 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
 
         if (n >= kMFLimit + 1) {
             const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
-            tab[hash13(rd32(in, 0))] = 0;
-            ip = 1;
+            // What the serial parser does between two sequences is a fixed list of table operations in
+            // position order: [insert ip-2] [re-test ip] probe s0, probe s0+1, ... (skip schedule).  Item t of
+            // that list goes to lane t - t0, so ONE round of LDS reads fetches every value the list needs, one
+            // round does the table reads+writes, one the candidate compares:
+            //   t = 0      insert `ins` (write only)         -- position 0 at the start of the block, else ip-2
+            //   t = 1      re-test of position ip            -- only after a match (a hit = sequence with no literals)
+            //   t >= 2     probe k = t-2 of the search starting at s0 (= ip+1 after a match, 1 at the start)
+            uint32_t ins = 0, s0 = 1;
+            bool has_retest = false;
 
             for (;;) { // one iteration per emitted sequence
-                uint32_t match = 0;
-                bool found = false;
+                uint32_t match = 0, mpos = 0;
+                bool found = false, exhausted = false;
+                for (uint32_t t0 = 0;;) {
+                    const uint32_t t = t0 + lane, k = t - 2;
+                    const bool is_probe = t >= 2;
+                    const uint32_t pos = t == 0 ? ins : t == 1 ? ip : s0 + probe_delta(k);
+                    // a probe runs iff the position after it stays <= mflimit + 1; later probes are dead
+                    const bool dead = is_probe && s0 + probe_delta(k + 1) > mflimit + 1;
+                    const bool active = !dead && (is_probe || t == 0 || has_retest);
+                    const uint32_t ndead = ctz64(__ballot(dead)); // first dead lane (64 = none)
+                    const unsigned long long amask = __ballot(active);
+                    if (!amask) { exhausted = true; break; }
 
-                // ---- search: lanes probe positions p0 + D(k0 + lane) ----
-                {
-                    const uint32_t p0 = ip;
-                    uint32_t k0 = 0;
-                    for (;;) {
-                        const uint32_t k = k0 + lane;
-                        const uint32_t pos = p0 + probe_delta(k);
-                        const bool valid = p0 + probe_delta(k + 1) <= mflimit + 1; // forwardIp > mflimitPlusOne stops
-                        const unsigned long long vmask = __ballot(valid);
-                        if (!(vmask & 1ull)) break; // the very next probe already runs off the end
-                        const uint32_t nvalid = ctz64(~vmask);
-
-                        uint32_t v = 0, h = 0, old = 0;
-                        if (valid) {
-                            v = rd32(in, pos);
-                            h = hash13(v);
-                            old = tab[h];
-                            tab[h] = (uint16_t)pos;
-                        }
-                        // a lane whose slot was overwritten by another lane of this batch shares its hash
-                        // (the barrier keeps hipcc from forwarding the lane's own store to the read-back)
-                        __syncthreads();
-                        const bool lost = valid && (tab[h] != (uint16_t)pos);
-                        uint32_t m = ctz64(__ballot(lost));
-                        if (m == 0) m = 1; // lane 0 read the table before any write of this batch
-                        const uint32_t L = m < nvalid ? m : nvalid;
-
-                        const bool eq = lane < L && rd32(in, old) == v;
-                        const unsigned long long eqmask = __ballot(eq);
-                        const uint32_t ncommit = eqmask ? ctz64(eqmask) + 1 : L;
-
-                        if (ncommit < nvalid) { // undo speculative writes, then re-assert the committed ones
-                            if (valid && lane >= ncommit) tab[h] = (uint16_t)old;
-                            if (lane < ncommit) tab[h] = (uint16_t)pos;
-                        }
-                        if (eqmask) {
-                            const uint32_t w = ctz64(eqmask);
-                            ip = __builtin_amdgcn_readlane(pos, w);
-                            match = __builtin_amdgcn_readlane(old, w);
-                            found = true;
-                            break;
-                        }
-                        if (L == nvalid && nvalid < 64) break; // next probe would pass the end of the block
-                        k0 += L;
+                    uint32_t v = 0, h = 0, old = 0;
+                    if (active) {
+                        v = rd32(in, pos);
+                        h = hash13(v);
+                        old = tab[h];
+                        tab[h] = (uint16_t)pos;
                     }
+                    // a lane whose slot was overwritten by another lane of this batch shares its hash
+                    // (the barrier keeps hipcc from forwarding the lane's own store to the read-back)
+                    __syncthreads();
+                    const bool lost = active && (tab[h] != (uint16_t)pos);
+                    const uint32_t fa = ctz64(amask);
+                    uint32_t m = ctz64(__ballot(lost));
+                    if (m == fa) m = fa + 1; // the first active lane read the table before any write of this batch
+                    const uint32_t L = m < ndead ? m : ndead;
+
+                    const bool eq = active && t != 0 && lane < L && rd32(in, old) == v;
+                    const unsigned long long eqmask = __ballot(eq);
+                    const uint32_t ncommit = eqmask ? ctz64(eqmask) + 1 : L;
+                    // undo speculative writes beyond the committed lanes, then re-assert the committed ones
+                    if (__ballot(active && lane >= ncommit)) {
+                        if (active && lane >= ncommit) tab[h] = (uint16_t)old;
+                        if (active && lane < ncommit) tab[h] = (uint16_t)pos;
+                    }
+                    if (eqmask) {
+                        const uint32_t w = ctz64(eqmask);
+                        mpos = __builtin_amdgcn_readlane(pos, w);
+                        match = __builtin_amdgcn_readlane(old, w);
+                        found = true;
+                        break;
+                    }
+                    if (ndead < 64 && L == ndead) { exhausted = true; break; } // the next probe would pass the end of the block
+                    t0 += L;
                 }
+                (void)exhausted;
                 if (!found) break; // -> last literals
+                ip = mpos;
 
-                // ---- catch up: extend the match backwards over pending literals ----
-                for (;;) {
-                    const uint32_t j = lane + 1;
-                    const bool ok = ip >= anchor + j && match >= j && in[ip - j] == in[match - j];
-                    const uint32_t cnt = ctz64(~__ballot(ok));
-                    ip -= cnt; match -= cnt;
-                    if (cnt < 64) break;
-                }
-
-                // ---- literal run ----
-                uint32_t tok_pos = op, token;
+                // ---- one round for both directions: lanes 0..47 extend forwards, lanes 48..63 backwards ----
+                uint32_t mc, back;
                 {
-                    const uint32_t lit = ip - anchor;
-                    op += 1;
-                    if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
-                    else token = lit << 4;
-                    copy_out(out + op, in, anchor, lit, lane);
-                    op += lit;
+                    bool ok;
+                    if (lane < 48) {
+                        const uint32_t i = ip + kMinMatch + lane;
+                        ok = i < matchlimit && in[i] == in[match + kMinMatch + lane];
+                    } else {
+                        const uint32_t j = lane - 47;
+                        ok = ip >= anchor + j && match >= j && in[ip - j] == in[match - j];
+                    }
+                    const unsigned long long okm = __ballot(ok);
+                    mc = ctz64(~okm | (1ull << 48)); // trailing ones within lanes 0..47
+                    back = ctz64(~(okm >> 48));
                 }
-
-                bool more;
-                do { // ---- one match (re-entered directly when the next position matches at once) ----
-                    const uint32_t off = ip - match;
-                    if (lane == 0) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
-                    op += 2;
-
-                    uint32_t mc = 0;
-                    const uint32_t a = ip + kMinMatch, b = match + kMinMatch;
+                if (mc == 48) { // long match: keep counting, 64 bytes per round
                     for (;;) {
-                        const uint32_t i = a + mc + lane;
-                        const bool ok = i < matchlimit && in[i] == in[b + mc + lane];
+                        const uint32_t i = ip + kMinMatch + mc + lane;
+                        const bool ok = i < matchlimit && in[i] == in[match + kMinMatch + mc + lane];
                         const uint32_t cnt = ctz64(~__ballot(ok));
                         mc += cnt;
                         if (cnt < 64) break;
                     }
-                    ip += kMinMatch + mc;
-                    if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
-                    else token += mc;
-                    if (lane == 0) out[tok_pos] = (uint8_t)token;
-                    anchor = ip;
-                    more = false;
-                    if (ip > mflimit) { found = false; break; } // end of parse: remaining bytes are literals
-
-                    tab[hash13(rd32(in, ip - 2))] = (uint16_t)(ip - 2);
-                    const uint32_t cur = rd32(in, ip), h = hash13(cur);
-                    match = uni(tab[h]);
-                    tab[h] = (uint16_t)ip;
-                    if (uni(rd32(in, match)) == uni(cur)) { // immediate match: a sequence with no literals
-                        tok_pos = op; op += 1; token = 0;
-                        more = true;
+                }
+                if (back == 16) { // long catch-up (rare)
+                    for (;;) {
+                        const uint32_t j = back + lane + 1;
+                        const bool ok = ip >= anchor + j && match >= j && in[ip - j] == in[match - j];
+                        const uint32_t cnt = ctz64(~__ballot(ok));
+                        back += cnt;
+                        if (cnt < 64) break;
                     }
-                } while (more);
-                if (!found) break;
-                ip += 1; // next search starts one past the re-tested position
+                }
+                const uint32_t mend = ip + kMinMatch + mc; // first byte after the match
+                ip -= back; match -= back; mc += back;     // LZ4_count restarts 4 bytes after the moved-back start
+
+                // ---- emit: literals [anchor, ip), offset, match length ----
+                if (ip < anchor || mend > n) { op = 0; anchor = n; break; } // cannot happen; never write out of bounds
+                const uint32_t lit = ip - anchor, tok_pos = op;
+                uint32_t token;
+                op += 1;
+                if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
+                else token = lit << 4;
+                copy_out(out + op, in, anchor, lit, lane);
+                op += lit;
+                const uint32_t off = ip - match;
+                if (lane == 0) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
+                op += 2;
+                if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
+                else token += mc;
+                if (lane == 0) out[tok_pos] = (uint8_t)token;
+
+                ip = mend;
+                anchor = ip;
+                if (ip > mflimit) break; // end of parse: remaining bytes are literals
+                ins = ip - 2; s0 = ip + 1; has_retest = true;
             }
         }
 
@@ -473,11 +491,12 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536 || nblocks > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
-    const uint32_t lds = ((n + 15u) & ~15u) + kTabBytes;
+    const uint32_t stage = n <= kStageMax ? 1u : 0u;
+    const uint32_t lds = kTabBytes + (stage ? ((n + 15u) & ~15u) : 0u);
     static bool attr_set = false; // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_blocks_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + kTabBytes);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStageMax + kTabBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -503,10 +522,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (phase == kLz4ProbeOnly || (mode && strcmp(mode, "scan") == 0)) return hipSuccess;
     // parse: queued blocks only; LDS admits 160 KiB / lds workgroups per CU
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
-    const size_t want = 256 * (per_cu > 8 ? 8 : per_cu);
+    const size_t want = 256 * (per_cu > 10 ? 10 : per_cu);
     const size_t grid = nblocks < want ? nblocks : want;
     hipLaunchKernelGGL(lz4_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes, queue, counters);
+                       dst_stride, sizes, queue, counters, stage);
     return hipGetLastError();
 }
 
