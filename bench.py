@@ -113,23 +113,37 @@ def main():
 
     src = torch.empty(nb * bs, dtype=torch.uint8, device="cuda")
     dst = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
-    digests = torch.zeros((nb, db), dtype=torch.uint8, device="cuda")
+    # two digest / totals buffers: step i's result gather (RCCL, async) overlaps step i+1's kernels
+    dig_bufs = [torch.zeros((nb, db), dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+    tot_bufs = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(len(dig_bufs))]
+    digests = dig_bufs[0]
     sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
-    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    pending = [[] for _ in dig_bufs]  # outstanding RCCL work per buffer
     cw.dev_gen_random(SEED, first, nb, bs, src.data_ptr(), s)  # this rank's blocks of the global stream
     torch.cuda.synchronize()
 
+    state = {"i": 0, "gathered": None}
+
     def step(timed: bool):
         cw.profile_enable(timed)  # the library brackets its own kernel launches with HIP events on their streams
+        b = state["i"] % len(dig_bufs)
+        state["i"] += 1
+        for h in pending[b]:      # the gather that last read this buffer must be done before it is overwritten
+            h.wait()
+        dig, totals = dig_bufs[b], tot_bufs[b]
         totals.zero_()
         # codec + hash side by side (ProcessBlock, :243-257); see cw_dev_hash_and_compress for the stream layout
-        cw.dev_hash_and_compress(args.hash, args.comp, src.data_ptr(), bs, nb, digests.data_ptr(), dst.data_ptr(),
+        cw.dev_hash_and_compress(args.hash, args.comp, src.data_ptr(), bs, nb, dig.data_ptr(), dst.data_ptr(),
                                  stride, sizes.data_ptr(), s)
         cw.dev_sum_sizes(sizes.data_ptr(), nb, bs, totals.data_ptr(), s)
         # the only exchange: gather digests + byte totals (no-op at N=1)
-        return gather_results(digests, totals, world, async_op=False)
+        all_d, all_t, pending[b] = gather_results(dig, totals, world, async_op=world > 1)
+        state["gathered"] = (all_d, all_t, dig)
 
     def fence():
+        for hs in pending:
+            for h in hs:
+                h.wait()
         if world > 1:
             import torch.distributed as dist
             dist.barrier(device_ids=[local_rank])
@@ -140,8 +154,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        all_digests, all_totals, _ = step(True)
+        step(True)
     fence()
+    all_digests, all_totals, digests = state["gathered"]
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
@@ -151,7 +166,6 @@ def main():
 
     prof = cw.profile_read(reset=True)
     k_ms = {"comp": prof["codec"][0] / max(prof["codec"][1], 1), "hash": prof["hash"][0] / max(prof["hash"][1], 1)}
-    parse_ms = prof["parse"][0] / max(prof["parse"][1], 1)
     total_blocks = nb * world
     bytes_out = int(all_totals[0].item())
     value = total_blocks * bs * args.steps / elapsed / 1e9
@@ -179,18 +193,10 @@ def main():
     # algorithmic bytes per block (DESIGN.md "Rooflines"): hash reads the block and writes its digest;
     # the codec reads the block and writes csize + 4
     csize = bytes_out / total_blocks
-    fused_raw = os.environ.get("CW_FUSED_RAW") == "1" and args.comp == "lz4" and args.hash.startswith("skein") and bs % 64 == 0
-    if fused_raw:
-        # the hash kernel also stores the literal run of every block (it holds the bytes in registers); the codec's
-        # scan kernel reads the block through its probes and writes only run headers + sizes
-        alg_bytes = {"hash": bs + db + bs, "comp": bs + (csize - bs) + 4}
-        names = {"hash": "cw::skein_lines_kernel<%d,true,true>" % (8 if args.hash == "skein512" else 4),
-                 "comp": "cw::lz4_scan_kernel<false>"}
-    else:
-        alg_bytes = {"hash": bs + db, "comp": bs + csize + 4}
-        names = {"hash": {"skein512": "cw::skein_lines_kernel<8,true,false>", "skein": "cw::skein_lines_kernel<4,true,false>",
-                          "sha256mb": "cw::sha256_blocks_kernel<true,false>"}[args.hash],
-                 "comp": "cw::lz4_scan_kernel<true> (+ cw::lz4_blocks_kernel on queued blocks)" if args.comp == "lz4" else "cw::lzf kernel"}
+    alg_bytes = {"hash": bs + db, "comp": bs + csize + 4}
+    names = {"hash": {"skein512": "cw::skein_lines_kernel<8,true>", "skein": "cw::skein_lines_kernel<4,true>",
+                      "sha256mb": "cw::sha256_blocks_kernel<true,false>"}[args.hash],
+             "comp": "cw::lz4_scan_kernel (+ cw::lz4_blocks_kernel on queued blocks)" if args.comp == "lz4" else "cw::lzf_blocks_kernel"}
     dom = max(k_ms, key=k_ms.get)
     kernels = {k: {"ms_per_launch": round(k_ms[k], 3),
                    "alg_GBps": round(alg_bytes[k] * nb / (k_ms[k] / 1e3) / 1e9, 1),
@@ -214,8 +220,7 @@ def main():
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "alg_bytes_per_block": round(alg_bytes[dom], 1)},
-        "kernels": dict(kernels, parse_queued={"ms_per_launch": round(parse_ms, 3)},
-                        note="codec scan and hash run concurrently on two streams; durations overlap"),
+        "kernels": dict(kernels, note="codec and hash run concurrently on two streams; durations overlap"),
         "parity_spot_check": spot,
     }
     if world == 1 and not args.no_cpu_baseline:

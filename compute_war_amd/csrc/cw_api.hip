@@ -44,7 +44,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 // ---- optional per-thread kernel timing (cw_profile_*): HIP events on the stream each kernel is launched on ----
-enum { PROF_CODEC = 0, PROF_HASH = 1, PROF_PARSE = 2, PROF_KINDS = 3 };
+enum { PROF_CODEC = 0, PROF_HASH = 1, PROF_OTHER = 2, PROF_KINDS = 3 };
 struct ProfSpan { int kind; hipEvent_t a, b; };
 thread_local bool t_prof_on = false;
 thread_local std::vector<ProfSpan> t_prof;
@@ -296,53 +296,13 @@ int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size
         return rc == CW_OK ? cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, stream) : rc;
     }
     if ((rc = t_side.open()) != CW_OK) return rc;
-    if (nblocks == 0) return CW_OK;
-    if (!d_src || !d_digests || !d_dst || !d_sizes) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
-    if ((rc = check_block(block_bytes)) != CW_OK) return rc;
-    if (src_stride < block_bytes) return fail(CW_ERR_BAD_ARG, "src_stride < block_bytes");
     hipStream_t main_s = (hipStream_t)stream;
-    const uint8_t *src = (const uint8_t *)d_src;
-    const int nw = hash_alg == CW_HASH_SKEIN512 ? 8 : hash_alg == CW_HASH_SKEIN256_128 ? 4 : 0;
-    // Skein + LZ4 on line-aligned blocks: the hash kernel, which pulls every byte of every block through its
-    // registers anyway, also stores them as the literal run of the block's LZ4 slot; the codec's scan then only
-    // probes (and writes run headers and sizes), and the parse of the blocks it queued -- whose output replaces the
-    // speculative literal run -- is issued after the join.
-    // Measured on MI355X (profiles/, DESIGN.md "What was tried"): the per-lane 16-byte stores this needs (64 different
-    // cache lines per store instruction) cost the hash kernel more than the codec's own coalesced copy saves, so the
-    // split is opt-in (CW_FUSED_RAW=1) until the hash kernel stages its lines through LDS.
-    static const char *raw_env = getenv("CW_FUSED_RAW");
-    const bool fused_raw = raw_env && raw_env[0] == '1' && comp_alg == CW_COMP_LZ4 && nw &&
-                           cw::skein_can_rawcopy(src, block_bytes, src_stride, nw);
-    if (comp_alg != CW_COMP_LZ4 && comp_alg != CW_COMP_LZF) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
-    if (dst_stride < cw_compress_bound(comp_alg, block_bytes))
-        return fail(CW_ERR_BAD_ARG, "dst_stride %zu < bound %zu", dst_stride, cw_compress_bound(comp_alg, block_bytes));
-
     HIP_TRY(hipEventRecord(t_side.fork, main_s));
     HIP_TRY(hipStreamWaitEvent(t_side.side, t_side.fork, 0));
-    if (fused_raw) {
-        hipError_t e;
-        {
-            ProfScope prof(PROF_CODEC, main_s);
-            e = cw::lz4_launch(src, block_bytes, src_stride, nblocks, (uint8_t *)d_dst, dst_stride, d_sizes, main_s, cw::kLz4ProbeOnly);
-        }
-        if (e != hipSuccess) return fail(CW_ERR_HIP, "lz4 scan launch: %s", hipGetErrorString(e));
-        cw::RawCopy raw;
-        raw.dst = (uint8_t *)d_dst; raw.stride = dst_stride; raw.hdr = cw::lz4_raw_header_bytes(block_bytes);
-        ProfScope prof(PROF_HASH, t_side.side);
-        e = nw == 8 ? cw::skein512_launch(src, block_bytes, src_stride, nblocks, g_iv512_512, (uint8_t *)d_digests, 64, t_side.side, raw)
-                    : cw::skein256_launch(src, block_bytes, src_stride, nblocks, g_iv256_128, (uint8_t *)d_digests, 16, t_side.side, raw);
-        if (e != hipSuccess) return fail(CW_ERR_HIP, "hash launch: %s", hipGetErrorString(e));
-    } else {
-        rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
-        if (rc == CW_OK) rc = cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, t_side.side);
-    }
+    rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
+    if (rc == CW_OK) rc = cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, t_side.side);
     HIP_TRY(hipEventRecord(t_side.join, t_side.side));
     HIP_TRY(hipStreamWaitEvent(main_s, t_side.join, 0));
-    if (rc == CW_OK && fused_raw) {
-        ProfScope prof(PROF_PARSE, main_s);
-        hipError_t e = cw::lz4_launch(src, block_bytes, src_stride, nblocks, (uint8_t *)d_dst, dst_stride, d_sizes, main_s, cw::kLz4ParseOnly);
-        if (e != hipSuccess) return fail(CW_ERR_HIP, "lz4 parse launch: %s", hipGetErrorString(e));
-    }
     return rc;
 }
 

@@ -18,22 +18,14 @@ struct SkeinIV { uint64_t w[8]; };
 void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv);
 
 // device launches (async on `stream`); src_stride = distance between consecutive blocks in bytes
-// raw_dst != nullptr: the hash kernel also stores each block's bytes at raw_dst + i*raw_stride + raw_hdr (the literal
-// run of an incompressible block in the codec's output slot); only valid when skein_can_rawcopy() says so.
-struct RawCopy { uint8_t *dst = nullptr; size_t stride = 0; uint32_t hdr = 0; };
-bool skein_can_rawcopy(const uint8_t *src, size_t block_bytes, size_t src_stride, int state_words);
 hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw = RawCopy());
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
 hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw = RawCopy());
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
 hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *digests,
                          hipStream_t stream);
-// phase: everything / scan that leaves the literal bytes of incompressible blocks to a RawCopy hash kernel and does not
-// parse / parse of the blocks the preceding scan on the same stream queued
-enum { kLz4All = 0, kLz4ProbeOnly = 1, kLz4ParseOnly = 2 };
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
-                      size_t dst_stride, uint32_t *sizes, hipStream_t stream, int phase = kLz4All);
-static inline uint32_t lz4_raw_header_bytes(size_t n) { return 1 + (n >= 15 ? (uint32_t)((n - 15) / 255) + 1 : 0); }
+                      size_t dst_stride, uint32_t *sizes, hipStream_t stream);
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream);
 hipError_t sum_sizes_launch(const uint32_t *sizes, size_t n, uint32_t raw_bytes, uint64_t *totals, hipStream_t stream);

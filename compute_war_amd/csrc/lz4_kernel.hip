@@ -202,10 +202,7 @@ __device__ __forceinline__ void scan_mark(uint32_t *sizes, size_t blk, uint32_t 
 }
 
 // Probes gather their 4 bytes from global memory (kScanGroup batches in flight per wavefront); a block in which
-// none matched is written as one literal run: header bytes here, and the literal bytes either here too
-// (COPY, one global->global copy) or -- when a hash kernel walks the same blocks anyway -- by that kernel,
-// which already holds every byte of every block in registers (skein_lines_kernel<.., RAW>).
-template <bool COPY>
+// none matched is written as one literal run (header bytes + one global->global copy).
 __global__ void __launch_bounds__(64)
 lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
                         uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nprobes,
@@ -257,7 +254,7 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
         } else if (lane == 0) {
             out[0] = (uint8_t)(n << 4);
         }
-        if (COPY) copy_g2g(out + op, g, n, lane);
+        copy_g2g(out + op, g, n, lane);
         if (lane == 0) sizes[blk] = op + n;
     }
 }
@@ -486,7 +483,7 @@ hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out)
 } // namespace
 
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
-                      size_t dst_stride, uint32_t *sizes, hipStream_t stream, int phase)
+                      size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536 || nblocks > 0xFFFFFFFFull) return hipErrorInvalidValue;
@@ -505,21 +502,15 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (e != hipSuccess) return e;
     uint32_t *counters = ws, *queue = ws + 4;
 
-    if (phase != kLz4ParseOnly) {
-        if ((e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
-        const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
-        if (phase == kLz4ProbeOnly)
-            hipLaunchKernelGGL(lz4_scan_kernel<false>, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride,
-                               nblocks, dst, dst_stride, sizes, scan_probes(n), queue, counters);
-        else
-            hipLaunchKernelGGL(lz4_scan_kernel<true>, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride,
-                               nblocks, dst, dst_stride, sizes, scan_probes(n), queue, counters);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
+    if ((e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
+    const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
+    hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
+                       dst_stride, sizes, scan_probes(n), queue, counters);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     // CW_LZ4_MODE=scan stops after the scan kernel (queued blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
     static const char *mode = getenv("CW_LZ4_MODE");
-    if (phase == kLz4ProbeOnly || (mode && strcmp(mode, "scan") == 0)) return hipSuccess;
+    if (mode && strcmp(mode, "scan") == 0) return hipSuccess;
     // parse: queued blocks only; LDS admits 160 KiB / lds workgroups per CU
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
     const size_t want = 256 * (per_cu > 10 ? 10 : per_cu);

@@ -48,10 +48,7 @@ static __device__ __forceinline__ uint64_t rotl(uint64_t x)
 #ifndef CW_ADD64_PAIR
 #define CW_ADD64_PAIR 0
 #endif
-// message prefetch distance of the line kernel: 0 = one 128-byte line ahead, 1 = two lines ahead (+32 VGPRs)
-#ifndef CW_SKEIN_PREFETCH2
-#define CW_SKEIN_PREFETCH2 0
-#endif
+
 static __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b)
 {
 #if CW_ADD64_PAIR
@@ -270,22 +267,21 @@ skein_blocks_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t 
 
 // ---------------------------------------------------------------------------------------------------
 // Hot instantiation for block sizes that are a positive multiple of the Threefish block (4096, 65536 ...).
-// Each lane fetches its message one 128-byte cache line at a time (8 x global_load_dwordx4 = 2
-// Threefish-512 steps or 4 Threefish-256 steps) so that every line crosses the memory system exactly
-// once -- fetching 64 B per step let ~40 % of the lines fall out of L2 between their two halves
-// (rocprofv3 FETCH_SIZE, profiles/) -- and the NEXT line is requested before the current line's 144 rounds
-// start, which hides HBM latency under ~5 us of integer work per wavefront.
+// Each lane fetches its message one 128-byte cache line at a time (8 x global_load_dwordx4 issued back to
+// back = 2 Threefish-512 steps or 4 Threefish-256 steps) so that every line crosses the memory system
+// exactly once -- fetching 64 B per step let ~40 % of the lines fall out of L2 between their two halves
+// (rocprofv3 FETCH_SIZE, profiles/).  Register budget: the line is held as two halves A and B plus one
+// spare half S.  When the steps of half A are done its registers are free, so the NEXT line is requested
+// right then -- first half into A, second half into S -- and lands while the steps of half B run; B <- S
+// afterwards.  48 message VGPRs instead of 64 keeps the kernel at ~100 VGPRs, which matters when codec
+// wavefronts share the SIMDs (4 hash wavefronts per SIMD still fit beside them).
 // ---------------------------------------------------------------------------------------------------
-// RAW: the lane also stores its block's bytes, as they pass through its registers, at raw.dst + i*raw.stride +
-// raw.hdr -- the literal run of the block in the LZ4 output slot, should the codec's scan find the block
-// incompressible (the scan writes the run's header bytes and the size; a block it queues for the parser is
-// simply overwritten later).  This saves the codec a second pass over every incompressible block.
-template <int NW, bool ALIGNED16, bool RAW>
+template <int NW, bool ALIGNED16>
 __global__ void __launch_bounds__(CW_SKEIN_THREADS)
 skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t src_stride, size_t nblocks,
-                   SkeinIV iv, uint8_t *__restrict__ digests, unsigned digest_bytes, RawCopy raw)
+                   SkeinIV iv, uint8_t *__restrict__ digests, unsigned digest_bytes)
 {
-    constexpr unsigned BB = NW * 8, SPL = 128 / BB; // steps per 128-byte line
+    constexpr unsigned BB = NW * 8, SPL = 128 / BB, HS = SPL / 2; // steps per line / per half line
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nblocks) return;
     const uint8_t *p = src + gid * src_stride;
@@ -298,14 +294,12 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     const size_t total = nmsg + 1;        // + output transform (skein.c:391-405), whose "message" is counter 0
     uint64_t t0 = 0, t1 = T1_FIRST | T1_MSG;
 
-    uint64_t cur[SPL][NW], nxt[SPL][NW];
-#if CW_SKEIN_PREFETCH2
-    uint64_t nx2[SPL][NW];
-#endif
-    auto fetch_line = [&](uint64_t (&dst)[SPL][NW], size_t line) {
+    uint64_t A[HS][NW], B[HS][NW], S[HS][NW];
+    // steps [first, first+HS) of the message into one half-line buffer; steps past the message read as zero
+    auto fetch_half = [&](uint64_t (&dst)[HS][NW], size_t first) {
 #pragma unroll
-        for (unsigned j = 0; j < SPL; j++) {
-            const size_t s = line * SPL + j;
+        for (unsigned j = 0; j < HS; j++) {
+            const size_t s = first + j;
             if (s < nmsg) {
                 load_words<NW, ALIGNED16>(dst[j], p + s * BB);
             } else {
@@ -314,30 +308,10 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
             }
         }
     };
-    fetch_line(cur, 0);
-
-    uint8_t *rawp = RAW ? raw.dst + gid * raw.stride + raw.hdr : nullptr;
-
-#pragma unroll 1
-    for (size_t line = 0; line * SPL < total; line++) {
-        fetch_line(nxt, line + 1);
-        if (RAW) {
+    auto run_half = [&](uint64_t (&buf)[HS][NW], size_t first) {
 #pragma unroll
-            for (unsigned j = 0; j < SPL; j++) {
-                const size_t s = line * SPL + j;
-                if (s < nmsg) {
-#pragma unroll
-                    for (int k = 0; k < NW / 2; k++) {
-                        const uint4 v = make_uint4((uint32_t)cur[j][2 * k], (uint32_t)(cur[j][2 * k] >> 32),
-                                                   (uint32_t)cur[j][2 * k + 1], (uint32_t)(cur[j][2 * k + 1] >> 32));
-                        __builtin_memcpy(rawp + s * BB + 16 * k, &v, 16); // unaligned global_store_dwordx4
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (unsigned j = 0; j < SPL; j++) {
-            const size_t s = line * SPL + j;
+        for (unsigned j = 0; j < HS; j++) {
+            const size_t s = first + j;
             if (s < total) {
                 if (s + 1 < nmsg) {
                     t0 += BB;
@@ -348,19 +322,24 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
                     t0 = 8;
                     t1 = T1_FIRST | T1_FINAL | T1_OUT;
                 }
-                Ubi<NW>::run(X, cur[j], t0, t1);
+                Ubi<NW>::run(X, buf[j], t0, t1);
                 t1 &= ~T1_FIRST;
             }
         }
+    };
+    fetch_half(A, 0);
+    fetch_half(B, HS);
+
+#pragma unroll 1
+    for (size_t first = 0; first < total; first += SPL) {
+        run_half(A, first);
+        fetch_half(A, first + SPL);      // the whole next line, requested together:
+        fetch_half(S, first + SPL + HS); //   first half into the freed A, second half into the spare
+        run_half(B, first + HS);
 #pragma unroll
-        for (unsigned j = 0; j < SPL; j++)
+        for (unsigned j = 0; j < HS; j++)
 #pragma unroll
-            for (int k = 0; k < NW; k++) {
-                cur[j][k] = nxt[j][k];
-#if CW_SKEIN_PREFETCH2
-                nxt[j][k] = nx2[j][k];
-#endif
-            }
+            for (int k = 0; k < NW; k++) B[j][k] = S[j][k];
     }
 
     uint8_t *out = digests + gid * digest_bytes;
@@ -377,7 +356,7 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 
 template <int NW>
 static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw)
+                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
     if ((digest_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(digests) & 15)) return hipErrorInvalidValue;
@@ -386,34 +365,27 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
     const bool ragged = block_bytes == 0 || (block_bytes % (NW * 8)) != 0;
 #define CW_LAUNCH(A, R) hipLaunchKernelGGL((skein_blocks_kernel<NW, A, R>), grid, block, 0, stream, \
                                            src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
-#define CW_LAUNCH_LINES(A, R) hipLaunchKernelGGL((skein_lines_kernel<NW, A, R>), grid, block, 0, stream, \
-                                                 src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, raw)
-    if (raw.dst && !(aligned && !ragged)) return hipErrorInvalidValue; // see skein_can_rawcopy()
-    if (aligned && !ragged && raw.dst) CW_LAUNCH_LINES(true, true);
-    else if (aligned && !ragged) CW_LAUNCH_LINES(true, false);
+#define CW_LAUNCH_LINES(A) hipLaunchKernelGGL((skein_lines_kernel<NW, A>), grid, block, 0, stream, \
+                                              src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
+    if (aligned && !ragged) CW_LAUNCH_LINES(true);
     else if (aligned) CW_LAUNCH(true, true);
-    else if (!ragged) CW_LAUNCH_LINES(false, false);
+    else if (!ragged) CW_LAUNCH_LINES(false);
     else CW_LAUNCH(false, true);
 #undef CW_LAUNCH
 #undef CW_LAUNCH_LINES
     return hipGetLastError();
 }
 
-bool skein_can_rawcopy(const uint8_t *src, size_t block_bytes, size_t src_stride, int nw)
-{
-    return block_bytes != 0 && block_bytes % ((size_t)nw * 8) == 0 && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
-}
-
 hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw)
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
 {
-    return launch_skein<8>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream, raw);
+    return launch_skein<8>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream);
 }
 
 hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, RawCopy raw)
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
 {
-    return launch_skein<4>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream, raw);
+    return launch_skein<4>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream);
 }
 
 // ---- host-side config-block UBI (Skein_*_Init's "no precomputed IV" path, skein.c:245-259) ----

@@ -147,11 +147,11 @@ def profile_enable(on: bool = True) -> None:
 
 
 def profile_read(reset: bool = True) -> dict:
-    """{'codec': (ms_sum, launches), 'hash': ..., 'parse': ...} from the library's own HIP events."""
+    """{'codec': (ms_sum, launches), 'hash': ..., 'other': ...} from the library's own HIP events."""
     ms = (C.c_double * 3)()
     cnt = (C.c_uint * 3)()
     check(lib().cw_profile_read(ms, cnt, 1 if reset else 0))
-    return {k: (ms[i], cnt[i]) for i, k in enumerate(("codec", "hash", "parse"))}
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(("codec", "hash", "other"))}
 
 
 # ---- HashOffload ------------------------------------------------------------------------------------

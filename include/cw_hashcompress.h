@@ -116,8 +116,7 @@ int cw_dev_sum_sizes(const uint32_t *d_sizes, size_t nblocks, uint32_t raw_bytes
 
 /* ---- kernel timing (the reference times with std::chrono around its calls, hash.cpp:11-18, HashAndCompress.cpp:397-406;
  *      device work is asynchronous, so the library brackets its own launches with HIP events on the stream each
- *      kernel is launched on).  Per calling thread.  Kinds: [0] codec scan (+parse when not split), [1] hash,
- *      [2] codec parse of the queued blocks (split path of cw_dev_hash_and_compress).                              */
+ *      kernel is launched on).  Per calling thread.  Kinds: [0] codec kernels, [1] hash kernel, [2] reserved.       */
 void cw_profile_enable(int on);
 int  cw_profile_read(double ms_sum[3], unsigned count[3], int reset);   /* synchronises on the recorded events */
 
