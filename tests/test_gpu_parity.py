@@ -259,6 +259,51 @@ def test_dev_hash_and_compress_matches_oracle(cw, oracle):
     assert int(totals[0]) == tot and int(totals[1]) == 0
 
 
+def test_dev_api_strides_and_misalignment(cw, oracle):
+    """Device entry points with src_stride > block_bytes, a source that is not 16-byte aligned and an odd dst_stride:
+    the generic (byte-granular) kernels must give the same bytes as the aligned fast paths."""
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    text = corpus_file("fields.c") + corpus_file("cp.html")
+    for bs, nb, sstride, shift in ((4096, 9, 4096 + 5, 3), (1000, 70, 1000, 1), (65536, 3, 65536 + 16, 0), (64, 130, 67, 7)):
+        raw = np.frombuffer((text * (sstride * nb // len(text) + 2))[:sstride * nb + shift], dtype=np.uint8).copy()
+        raw[::7] ^= np.arange(len(raw[::7]), dtype=np.uint8)       # make blocks differ
+        dev = torch.from_numpy(raw).cuda()
+        base = dev.data_ptr() + shift
+        blocks = [raw[shift + i * sstride: shift + i * sstride + bs].tobytes() for i in range(nb)]
+        for alg, db in HASHES:
+            dig = torch.zeros(nb * db + 16, dtype=torch.uint8, device="cuda")
+            cw.dev_hash(alg, base, bs, nb, dig.data_ptr(), s, src_stride=sstride)
+            torch.cuda.synchronize()
+            hd = dig.cpu().numpy()
+            for i in range(nb):
+                assert hd[i * db:(i + 1) * db].tobytes() == _oracle_hash(oracle, alg, blocks[i]), (alg, bs, i)
+        for comp, ref in (("lz4", oracle.lz4_compress), ("lzf", oracle.lzf_compress)):
+            dstride = cw.compress_bound(comp, bs) + 3
+            dst = torch.zeros(nb * dstride + 64, dtype=torch.uint8, device="cuda")
+            sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            cw.dev_compress(comp, base, bs, nb, dst.data_ptr() + 1, dstride, sizes.data_ptr(), s, src_stride=sstride)
+            torch.cuda.synchronize()
+            hz, hdst = sizes.cpu().numpy(), dst.cpu().numpy()
+            for i in range(nb):
+                want = ref(blocks[i])
+                assert hz[i] == len(want) and hdst[1 + i * dstride: 1 + i * dstride + len(want)].tobytes() == want, (comp, bs, i)
+
+
+def test_bad_arguments_are_errors(cw):
+    import torch
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(cw.CwError):
+        cw.dev_hash(9, buf.data_ptr(), 4096, 4, buf.data_ptr(), 0)              # unknown algorithm
+    with pytest.raises(cw.CwError):
+        cw.dev_hash("skein", buf.data_ptr(), 70000, 1, buf.data_ptr(), 0)        # block too large
+    with pytest.raises(cw.CwError):
+        cw.dev_compress("lz4", buf.data_ptr(), 4096, 4, buf.data_ptr(), 100, buf.data_ptr(), 0)   # dst_stride < bound
+    with pytest.raises(cw.CwError):
+        cw.dev_hash("skein", 0, 4096, 4, buf.data_ptr(), 0)                      # NULL source
+    cw.dev_hash("skein", buf.data_ptr(), 4096, 0, buf.data_ptr(), 0)             # zero blocks: no-op
+
+
 def test_hash_offload_lifecycle(cw, oracle):
     """HashOffload state machine (HashOffload.h:13-64) and the offload thread (:160-183)."""
     bs, nb = 4096, 32
