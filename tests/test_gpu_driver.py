@@ -1,0 +1,74 @@
+"""The C host driver (compute_war_amd/host/hashandcompress.c, the reference's main() re-stated over the C ABI)
+and the hashing_perf harness, run as subprocesses on the GPU box and checked against the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, corpus_file
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "compute_war_amd", "host", "hashandcompress")
+PERF = os.path.join(ROOT, "compute_war_amd", "host", "hashing_perf")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def build_host():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "compute_war_amd", "host")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def _expected(oracle, files, bs, rbf, hash_alg, comp):
+    unit = bs * rbf
+    out_total, fold, nblocks = 0, np.uint64(0), 0
+    for f in files:
+        data = corpus_file(f)
+        for u in range(len(data) // unit):          # a partial last read unit is dropped (HashAndCompress.cpp:207-210)
+            for b in range(rbf):
+                blk = data[u * unit + b * bs: u * unit + (b + 1) * bs]
+                c = oracle.lz4_compress(blk) if comp == "lz4" else oracle.lzf_compress(blk)
+                out_total += len(c) if c else bs
+                d = {"skein": lambda x: oracle.skein256(x, 128), "skein512": lambda x: oracle.skein512(x, 512),
+                     "sha256mb": oracle.sha256}[hash_alg](blk)
+                fold ^= np.bitwise_xor.reduce(np.frombuffer(d, dtype="<u8"))
+                nblocks += 1
+    return nblocks, out_total, int(fold)
+
+
+@pytest.mark.parametrize("offload", ["true", "false"])
+@pytest.mark.parametrize("hash_alg,comp,bs,rbf", [("skein", "lz4", 4096, 1), ("sha256mb", "lzf", 4096, 8),
+                                                  ("skein512", "lz4", 65536, 1)])
+def test_driver_report_and_totals(oracle, offload, hash_alg, comp, bs, rbf):
+    files = ["alice29.txt", "fields.c", "sum"] if offload == "false" else ["alice29.txt", "kennedy.xls", "ptt5", "sum"]
+    paths = [os.path.join(GOLDEN, "corpus", "canterbury", f) for f in files]
+    r = subprocess.run([EXE, "-v", f"--gpu-offload={offload}", "--c-threads=3", f"--read-blocks={rbf}", f"--block-size={bs}",
+                        f"--hash-alg={hash_alg}", f"--comp-alg={comp}"] + paths, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    # the reference's report line: hash|comp|totalTimeMS|throughputMBPS (HashAndCompress.cpp:409-412)
+    assert re.fullmatch(rf"{hash_alg}\|{comp}\|\d+\|\d+", lines[0]), lines[0]
+    m = re.fullmatch(r"blocks=(\d+) in=(\d+) out=(\d+) fold=([0-9a-f]{16})", lines[1])
+    nblocks, out_total, fold = _expected(oracle, files, bs, rbf, hash_alg, comp)
+    assert (int(m[1]), int(m[2]), int(m[3]), int(m[4], 16)) == (nblocks, nblocks * bs, out_total, fold)
+
+
+def test_driver_usage_errors():
+    r = subprocess.run([EXE, "--hash-alg=md5", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "invalid hashing algorithm" in r.stderr
+
+
+def test_hashing_perf_log_format(tmp_path):
+    d = tmp_path / "data"
+    d.mkdir()
+    (d / "a.bin").write_bytes(corpus_file("alice29.txt")[:5 * 4096 + 100])
+    r = subprocess.run([PERF, str(d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    sb = [l for l in lines if "|Skein256|" in l or "|Sha256|" in l]
+    mb = [l for l in lines if "|Sha256MB|" in l]
+    assert len(sb) == 10                                   # 5 whole blocks x 2 algorithms (test.cpp:19-23)
+    assert [l.split("|")[1] for l in sb] == [str(i) for i in range(10)]
+    assert len(mb) == sum(5 // w for w in range(1, 65))    # windows 1..64 (test.cpp:87-90)
+    assert all(re.fullmatch(r".+\|\d+\|Sha256MB\|\d+\|\d+\|", l) for l in mb)
