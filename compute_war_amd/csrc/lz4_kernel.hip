@@ -259,6 +259,157 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Streaming scan (16-byte aligned source, n a multiple of 16): the block crosses the memory system ONCE.
+// The wavefront walks the block in 4 KiB chunks (4 coalesced 16-byte loads per lane), three register sets in
+// rotation: chunk c+2 is being loaded while chunk c is written into a two-chunk LDS ring and the probes
+// that fall into chunk c-1 read their 4 bytes from that ring (an LDS round trip instead of a gather from
+// memory; a probe may straddle into the next chunk, which is why probing lags staging by one chunk).  When
+// Chunks are stored from their registers to their place in the literal run (the run's header shifts them by
+// 258 bytes, hence unaligned 16-byte stores).  A block is abandoned and queued for the parser at its first
+// hit, so compressible data costs a chunk or two of reads and at most one chunk of wasted stores here.
+// LDS: 32 KiB table + 8 KiB ring = 40 KiB -> 4 wavefronts per CU.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kChunk = 4096, kPieces = kChunk / 1024, kRing = 2 * kChunk, kStreamGroup = 4;
+
+struct Chunk { uint4 p[kPieces]; }; // 4 KiB of the block across the wavefront: piece j, lane L = bytes [j*1024 + L*16, +16)
+
+__device__ __forceinline__ void chunk_load(Chunk &r, const uint8_t *g, uint32_t c, uint32_t nchunks, uint32_t n, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t j = 0; j < kPieces; j++) {
+        const uint32_t off = c * kChunk + j * 1024 + lane * 16;
+        if (c < nchunks && off < n) r.p[j] = *reinterpret_cast<const uint4 *>(g + off);
+    }
+}
+__device__ __forceinline__ void chunk_stage(const Chunk &r, uint32_t *ring32, uint32_t c, uint32_t n, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t j = 0; j < kPieces; j++) {
+        const uint32_t off = c * kChunk + j * 1024 + lane * 16;
+        if (off < n) *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(ring32) + (off & (kRing - 1))) = r.p[j];
+    }
+}
+__device__ __forceinline__ void chunk_store(const Chunk &r, uint8_t *lit, uint32_t c, uint32_t n, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t j = 0; j < kPieces; j++) {
+        const uint32_t off = c * kChunk + j * 1024 + lane * 16;
+        if (off < n) { // four dword stores at a 2-byte-misaligned address: hipcc merges them into one global_store_dwordx4
+            uint32_t *q = reinterpret_cast<uint32_t *>(lit + off);
+            __builtin_nontemporal_store(r.p[j].x, q);
+            __builtin_nontemporal_store(r.p[j].y, q + 1);
+            __builtin_nontemporal_store(r.p[j].z, q + 2);
+            __builtin_nontemporal_store(r.p[j].w, q + 3);
+        }
+    }
+}
+
+struct Walk { // progress of one block's no-match walk
+    ScanState st;
+    uint32_t knext = 0, v0 = 0; // first probe that has not run yet; bytes 0..3 of the block
+    bool marked = false;
+};
+
+// run every probe whose position is < end (their bytes, incl. a straddle of up to 3, are in the ring)
+__device__ __forceinline__ void probe_upto(Walk &w, uint32_t end, uint32_t *tab, const uint32_t *ring32, uint32_t tag, uint32_t epoch,
+                                           uint32_t nprobes, const uint8_t *g, uint32_t lane)
+{
+    for (;;) {
+        uint32_t pos[kStreamGroup], v[kStreamGroup], nact = 0;
+        bool act[kStreamGroup];
+#pragma unroll
+        for (uint32_t j = 0; j < kStreamGroup; j++) {
+            const uint32_t k = w.knext + 64 * j + lane;
+            pos[j] = 1 + probe_delta(k);
+            act[j] = k < nprobes && pos[j] < end;
+            // unaligned 4 bytes out of the ring: two aligned dwords (the second may wrap) + byte align
+            const uint32_t a0 = (pos[j] & (kRing - 1)) >> 2, a1 = (a0 + 1) & (kRing / 4 - 1);
+            v[j] = act[j] ? __builtin_amdgcn_alignbyte(ring32[a1], ring32[a0], pos[j] & 3u) : 0u;
+            nact += (uint32_t)__builtin_popcountll(__ballot(act[j]));
+        }
+        if (nact == 0) return;
+#pragma unroll
+        for (uint32_t j = 0; j < kStreamGroup; j++) scan_probe(tab, tag, epoch, w.v0, pos[j], v[j], act[j], w.st);
+        w.marked = scan_settle(g, w.st);
+        w.knext += nact;
+        if (w.marked || nact < 64 * kStreamGroup) return;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+lz4_scan_stream_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
+                       uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nprobes,
+                       uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
+    __shared__ __attribute__((aligned(16))) uint32_t ring32[kRing / 4];
+    const uint32_t lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t epoch = 15;
+    const uint32_t nchunks = (n + kChunk - 1) / kChunk;
+    const uint32_t hdr = 1 + (n >= 15 ? (n - 15) / 255 + 1 : 0); // token + length bytes of the single literal run
+
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        scan_begin_block(tab, epoch, lane);
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride, *lit = out + hdr;
+        const uint32_t tag = epoch << 28;
+        Walk w;
+        Chunk r0, r1, r2; // chunk c lives in register set c % 3
+
+        // One pipeline stage: chunk c is in CUR, chunk c-1 in PREV.  PREV is stored first -- speculatively, its probes
+        // run at the end of this stage; a block that is queued after all is overwritten by the parser and wastes at
+        // most this one chunk of writes -- so that its registers can take the loads of chunk c+2 now, two stages
+        // before they are needed.
+#define CW_STAGE(PREV, CUR, C)                                                                         \
+        do {                                                                                           \
+            const uint32_t c_ = (C);                                                                   \
+            if (c_) chunk_store(PREV, lit, c_ - 1, n, lane);                                           \
+            chunk_load(PREV, g, c_ + 2, nchunks, n, lane);                                             \
+            chunk_stage(CUR, ring32, c_, n, lane);                                                     \
+            if (c_ == 0) {                                                                             \
+                w.v0 = ring32[0];                                                                      \
+                if (nprobes && lane == 0) {                                                            \
+                    const uint32_t h0 = w.v0 * 2654435761u;                                            \
+                    atomicMax(&tab[h0 >> 19], tag | ((h0 >> 7) & 0xFFFu)); /* position 0 */            \
+                }                                                                                      \
+            } else {                                                                                   \
+                probe_upto(w, c_ * kChunk, tab, ring32, tag, epoch, nprobes, g, lane);                 \
+            }                                                                                          \
+        } while (0)
+
+        chunk_load(r0, g, 0, nchunks, n, lane);
+        chunk_load(r1, g, 1, nchunks, n, lane);
+        for (uint32_t c = 0; c < nchunks && !w.marked; c += 3) {
+            CW_STAGE(r2, r0, c);
+            if (c + 1 < nchunks && !w.marked) CW_STAGE(r0, r1, c + 1);
+            if (c + 2 < nchunks && !w.marked) CW_STAGE(r1, r2, c + 2);
+        }
+#undef CW_STAGE
+        if (!w.marked) { // the last chunk: its probes end 12 bytes before the block does, nothing straddles
+            probe_upto(w, n, tab, ring32, tag, epoch, nprobes, g, lane);
+            if (!w.marked) {
+                const uint32_t last = (nchunks - 1) % 3;
+                if (last == 0) chunk_store(r0, lit, nchunks - 1, n, lane);
+                else if (last == 1) chunk_store(r1, lit, nchunks - 1, n, lane);
+                else chunk_store(r2, lit, nchunks - 1, n, lane);
+            }
+        }
+        if (w.marked) {
+            scan_mark(sizes, blk, queue, counters, lane);
+            continue;
+        }
+        if (n >= 15) {
+            if (lane == 0) out[0] = 15u << 4;
+            put_len(out + 1, n - 15, lane);
+        } else if (lane == 0) {
+            out[0] = (uint8_t)(n << 4);
+        }
+        if (lane == 0) sizes[blk] = hdr + n;
+    }
+}
+
 // number of probes of a no-match walk over n bytes (host)
 static uint32_t scan_probes(uint32_t n)
 {
@@ -503,13 +654,21 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     uint32_t *counters = ws, *queue = ws + 4;
 
     if ((e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
-    // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
-    const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
-    hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes, scan_probes(n), queue, counters);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     // CW_LZ4_MODE=scan stops after the scan kernel (queued blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
     static const char *mode = getenv("CW_LZ4_MODE");
+    // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
+    const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
+    // CW_LZ4_MODE=generic forces the gather-based scan (profiling knob)
+    const bool streamable = ((reinterpret_cast<uintptr_t>(src) | src_stride | n) & 15) == 0 && !(mode && strcmp(mode, "generic") == 0);
+    if (streamable) {
+        const size_t sgrid = nblocks < 256 * 4 ? nblocks : 256 * 4; // 40 KiB of LDS each -> 4 per CU
+        hipLaunchKernelGGL(lz4_scan_stream_kernel, dim3((unsigned)sgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
+                           dst_stride, sizes, scan_probes(n), queue, counters);
+    } else {
+        hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
+                           dst_stride, sizes, scan_probes(n), queue, counters);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if (mode && strcmp(mode, "scan") == 0) return hipSuccess;
     // parse: queued blocks only; LDS admits 160 KiB / lds workgroups per CU
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
