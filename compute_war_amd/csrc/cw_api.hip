@@ -306,6 +306,21 @@ int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size
     return rc;
 }
 
+int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, const uint32_t *d_sizes, size_t nblocks, void *d_dst,
+                      size_t block_bytes, uint32_t *d_status, void *stream)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    if (nblocks == 0) return CW_OK;
+    if (!d_comp || !d_sizes || !d_dst || !d_status) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
+    if (comp_alg != CW_COMP_LZ4 && comp_alg != CW_COMP_LZF) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
+    if (block_bytes == 0 || (rc = check_block(block_bytes)) != CW_OK) return rc ? rc : fail(CW_ERR_BAD_ARG, "block_bytes == 0");
+    hipError_t e = cw::decompress_launch(comp_alg == CW_COMP_LZ4 ? 0 : 1, (const uint8_t *)d_comp, comp_stride, d_sizes, nblocks,
+                                         (uint8_t *)d_dst, block_bytes, d_status, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CW_ERR_HIP, "decompress launch: %s", hipGetErrorString(e));
+    return CW_OK;
+}
+
 int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, void *d_dst, void *stream)
 {
     int rc = ensure_init();

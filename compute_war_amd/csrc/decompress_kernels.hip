@@ -1,0 +1,136 @@
+// decompress_kernels.hip -- LZ4-block and LZF decoders for gfx950, one compressed block per wavefront.
+//
+// The reference decompresses only to time it (LZ4_decompress_safe / lzf_decompress in
+// src/compression_perf/src/experiment.cpp:118,256).  Here the decoders are the
+// reference-independent verifier of the compressors at full scale: encode -> decode -> compare on the device.
+// Format-level decoders (LZ4 block format; LZF stream format, src/compression_perf/include/lzf/lzf.h:83-95),
+// bounds-checked like the "safe" variants: a malformed or truncated input gives status 1, never an
+// out-of-bounds access.
+//
+// A wavefront decodes its block into LDS (sequences are serial, their byte copies are 64 lanes wide; an
+// overlapping match -- offset < length -- is copied in rounds of `offset` bytes) and then streams the block out.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cw_device.h"
+
+namespace cw {
+
+namespace {
+__device__ __forceinline__ uint32_t bcast(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// out[op .. op+len) = out[op-off ..): overlapping copy, `off` bytes per round at most
+__device__ __forceinline__ void copy_match(uint8_t *out, uint32_t op, uint32_t off, uint32_t len, uint32_t lane)
+{
+    const uint32_t round = off < 64 ? off : 64;
+    for (uint32_t done = 0; done < len; done += round) {
+        const uint32_t k = done + lane;
+        uint8_t b = 0;
+        const bool act = lane < round && k < len;
+        if (act) b = out[op + k - off];
+        __syncthreads(); // all reads of this round before its writes (and LDS ordering across rounds)
+        if (act) out[op + k] = b;
+        __syncthreads();
+    }
+}
+} // namespace
+
+// status[i]: 0 = ok and exactly block_bytes produced, 1 = malformed / wrong size.  sizes[i] == 0 (LZF "did not
+// fit") means the block was stored raw: it is copied through when raw_src is given, else flagged.
+template <int ALG> // 0 = LZ4, 1 = LZF
+__global__ void __launch_bounds__(64)
+decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const uint32_t *__restrict__ sizes, size_t nblocks,
+                  uint8_t *__restrict__ dst, uint32_t block_bytes, uint32_t *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t out[]; // block_bytes
+    const uint32_t lane = threadIdx.x;
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const uint8_t *in = comp + blk * comp_stride;
+        const uint32_t n = sizes[blk];
+        uint32_t ip = 0, op = 0;
+        bool bad = n == 0;
+        __syncthreads();
+        if (ALG == 0) {
+            while (!bad) {
+                if (ip >= n) { bad = true; break; }
+                const uint32_t tok = bcast(in[ip]); ip++;
+                uint32_t lit = tok >> 4;
+                if (lit == 15) {
+                    uint32_t c;
+                    do { if (ip >= n) { bad = true; break; } c = bcast(in[ip]); ip++; lit += c; } while (c == 255);
+                    if (bad) break;
+                }
+                if (ip + lit > n || op + lit > block_bytes) { bad = true; break; }
+                for (uint32_t i = lane; i < lit; i += 64) out[op + i] = in[ip + i];
+                ip += lit; op += lit;
+                if (ip == n) break; // last sequence: literals only
+                if (ip + 2 > n) { bad = true; break; }
+                const uint32_t off = bcast((uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8)); ip += 2;
+                if (off == 0 || off > op) { bad = true; break; }
+                uint32_t ml = tok & 15;
+                if (ml == 15) {
+                    uint32_t c;
+                    do { if (ip >= n) { bad = true; break; } c = bcast(in[ip]); ip++; ml += c; } while (c == 255);
+                    if (bad) break;
+                }
+                ml += 4;
+                if (op + ml > block_bytes) { bad = true; break; }
+                copy_match(out, op, off, ml, lane);
+                op += ml;
+            }
+        } else {
+            while (!bad && ip < n) {
+                const uint32_t ctrl = bcast(in[ip]); ip++;
+                if (ctrl < 32) {
+                    const uint32_t run = ctrl + 1;
+                    if (ip + run > n || op + run > block_bytes) { bad = true; break; }
+                    if (lane < run) out[op + lane] = in[ip + lane];
+                    ip += run; op += run;
+                } else {
+                    uint32_t len = ctrl >> 5;
+                    if (ip >= n) { bad = true; break; }
+                    if (len == 7) { len += bcast(in[ip]); ip++; if (ip >= n) { bad = true; break; } }
+                    const uint32_t off = (((ctrl & 0x1f) << 8) | bcast(in[ip])) + 1; ip++;
+                    len += 2;
+                    if (off > op || op + len > block_bytes) { bad = true; break; }
+                    copy_match(out, op, off, len, lane);
+                    op += len;
+                }
+            }
+        }
+        __syncthreads();
+        if (op != block_bytes) bad = true;
+        if (!bad) {
+            uint8_t *d = dst + blk * (size_t)block_bytes;
+            for (uint32_t i = lane; i < block_bytes; i += 64) d[i] = out[i];
+        }
+        if (lane == 0) status[blk] = bad ? 1u : 0u;
+    }
+}
+
+hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, uint8_t *dst,
+                             size_t block_bytes, uint32_t *status, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    if (block_bytes == 0 || block_bytes > 65536) return hipErrorInvalidValue;
+    const uint32_t lds = (uint32_t)((block_bytes + 15) & ~(size_t)15);
+    const size_t per_cu = (160u * 1024u) / lds;
+    const size_t want = 256 * (per_cu > 8 ? 8 : per_cu ? per_cu : 1), grid = nblocks < want ? nblocks : want;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(decompress_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(decompress_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (alg == 0)
+        hipLaunchKernelGGL(decompress_kernel<0>, dim3((unsigned)grid), dim3(64), lds, stream, comp, comp_stride, sizes, nblocks, dst,
+                           (uint32_t)block_bytes, status);
+    else
+        hipLaunchKernelGGL(decompress_kernel<1>, dim3((unsigned)grid), dim3(64), lds, stream, comp, comp_stride, sizes, nblocks, dst,
+                           (uint32_t)block_bytes, status);
+    return hipGetLastError();
+}
+
+} // namespace cw

@@ -134,6 +134,11 @@ def dev_hash_and_compress(hash_alg, comp_alg, d_src: int, block_bytes: int, nblo
                                          src_stride or block_bytes, nblocks, d_digests, d_dst, dst_stride, d_sizes, stream))
 
 
+def dev_decompress(alg, d_comp: int, comp_stride: int, d_sizes: int, nblocks: int, d_dst: int, block_bytes: int,
+                   d_status: int, stream: int = 0) -> None:
+    check(lib().cw_dev_decompress(_comp_id(alg), d_comp, comp_stride, d_sizes, nblocks, d_dst, block_bytes, d_status, stream))
+
+
 def dev_gen_random(seed: int, first_block: int, nblocks: int, block_bytes: int, d_dst: int, stream: int = 0) -> None:
     check(lib().cw_dev_gen_random(seed, first_block, nblocks, block_bytes, d_dst, stream))
 

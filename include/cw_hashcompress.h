@@ -107,6 +107,12 @@ int cw_dev_compress(int comp_alg, const void *d_src, size_t block_bytes, size_t 
 int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size_t block_bytes,
                              size_t src_stride, size_t nblocks, void *d_digests, void *d_dst,
                              size_t dst_stride, uint32_t *d_sizes, void *stream);
+/* Decoders (the reference calls LZ4_decompress_safe / lzf_decompress only to time them,
+ * src/compression_perf/src/experiment.cpp:118,256): decode nblocks compressed slots (comp_stride apart, d_sizes[i]
+ * bytes each) into nblocks * block_bytes at d_dst; d_status[i] = 0 iff slot i is well formed and yields exactly
+ * block_bytes.  Used as the reference-independent round-trip verifier of the compressors.                     */
+int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, const uint32_t *d_sizes, size_t nblocks,
+                      void *d_dst, size_t block_bytes, uint32_t *d_status, void *stream);
 /* synthetic input: u64 word w of block b = splitmix64(seed ^ (b << 13 | w)) */
 int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes,
                       void *d_dst, void *stream);
