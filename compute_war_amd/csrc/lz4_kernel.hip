@@ -422,12 +422,13 @@ static uint32_t scan_probes(uint32_t n)
 
 // Parse kernel: the full greedy parse of the blocks the scan queued (queue[0 .. counters[1]); counters[0] is the
 // shared head the workgroups pull from, so a handful of queued blocks spreads over as many workgroups).
+template <bool STAGED>
 __global__ void __launch_bounds__(64)
 lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
                   uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes,
-                  const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t stage)
+                  const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
 {
-    // LDS: the 16 KiB position table, then (stage != 0) the block itself.  Small blocks are staged: every read of
+    // LDS: the 16 KiB position table, then (STAGED) the block itself.  Small blocks are staged: every read of
     // the parse is then an LDS read.  Large blocks are read through L1/L2 instead: with only the table in LDS ten
     // blocks fit a CU instead of two, and the parse -- one wavefront per block, bound by its own instruction
     // issue and dependent round trips -- gains more from the extra wavefronts than it loses to the longer reads.
@@ -452,8 +453,10 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
 
         // ---- stage the block into LDS (coalesced 16 B per lane) and clear the table ----
         __syncthreads(); // previous block's readers are done
-        const uint8_t *in = g;
-        if (stage) {
+        // `in` is purely an LDS pointer or purely a global one (template), so every read below is a ds_read or a
+        // global_load, never a flat access
+        const uint8_t *in = STAGED ? lds_in : g;
+        if (STAGED) {
             if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
                 const uint4 *g4 = reinterpret_cast<const uint4 *>(g);
                 const uint32_t nvec = n >> 4;
@@ -462,7 +465,6 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
             } else {
                 for (uint32_t i = lane; i < n; i += 64) lds_in[i] = g[i];
             }
-            in = lds_in;
         }
         for (uint32_t i = lane; i < kTabBytes / 16; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
@@ -481,15 +483,17 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
             uint32_t ins = 0, s0 = 1;
             bool has_retest = false;
 
-            for (;;) { // one iteration per emitted sequence
+            for (uint32_t seq = 0; seq < n; seq++) { // one iteration per emitted sequence (a block has < n of them)
                 uint32_t match = 0, mpos = 0;
                 bool found = false, exhausted = false;
                 for (uint32_t t0 = 0;;) {
                     const uint32_t t = t0 + lane, k = t - 2;
                     const bool is_probe = t >= 2;
-                    const uint32_t pos = t == 0 ? ins : t == 1 ? ip : s0 + probe_delta(k);
+                    // the first 65 probes of a search advance by 1, so the head batch needs no closed form
+                    const uint32_t dk = t0 == 0 ? k : probe_delta(k), stepk = k == 0 ? 1u : (63u + k) >> 6;
+                    const uint32_t pos = t == 0 ? ins : t == 1 ? ip : s0 + dk;
                     // a probe runs iff the position after it stays <= mflimit + 1; later probes are dead
-                    const bool dead = is_probe && s0 + probe_delta(k + 1) > mflimit + 1;
+                    const bool dead = is_probe && s0 + dk + stepk > mflimit + 1;
                     const bool active = !dead && (is_probe || t == 0 || has_retest);
                     const uint32_t ndead = ctz64(__ballot(dead)); // first dead lane (64 = none)
                     const unsigned long long amask = __ballot(active);
@@ -578,12 +582,15 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
                 else token = lit << 4;
                 copy_out(out + op, in, anchor, lit, lane);
                 op += lit;
-                const uint32_t off = ip - match;
-                if (lane == 0) { out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8); }
+                const uint32_t off = ip - match, off_pos = op;
                 op += 2;
                 if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
                 else token += mc;
-                if (lane == 0) out[tok_pos] = (uint8_t)token;
+                if (lane < 3) { // token and the two offset bytes: three lanes, one store instruction
+                    const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
+                    const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
+                    out[where] = (uint8_t)what;
+                }
 
                 ip = mend;
                 anchor = ip;
@@ -639,11 +646,11 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536 || nblocks > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
-    const uint32_t stage = n <= kStageMax ? 1u : 0u;
-    const uint32_t lds = kTabBytes + (stage ? ((n + 15u) & ~15u) : 0u);
+    const bool staged = n <= kStageMax;
+    const uint32_t lds = kTabBytes + (staged ? ((n + 15u) & ~15u) : 0u);
     static bool attr_set = false; // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_blocks_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_blocks_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kStageMax + kTabBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -674,8 +681,12 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
     const size_t want = 256 * (per_cu > 10 ? 10 : per_cu);
     const size_t grid = nblocks < want ? nblocks : want;
-    hipLaunchKernelGGL(lz4_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes, queue, counters, stage);
+    if (staged)
+        hipLaunchKernelGGL(lz4_blocks_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                           dst_stride, sizes, queue, counters);
+    else
+        hipLaunchKernelGGL(lz4_blocks_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                           dst_stride, sizes, queue, counters);
     return hipGetLastError();
 }
 
