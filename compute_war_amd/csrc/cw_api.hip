@@ -151,13 +151,13 @@ int check_block(size_t block_bytes)
     return CW_OK;
 }
 
-int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, uint8_t *d_dig, hipStream_t s)
+int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, uint8_t *d_dig, hipStream_t s, bool lean = false)
 {
     hipError_t e;
     ProfScope prof(PROF_HASH, s);
     switch (alg) {
-    case CW_HASH_SKEIN512: e = cw::skein512_launch(d_src, bb, stride, n, g_iv512_512, d_dig, 64, s); break;
-    case CW_HASH_SKEIN256_128: e = cw::skein256_launch(d_src, bb, stride, n, g_iv256_128, d_dig, 16, s); break;
+    case CW_HASH_SKEIN512: e = cw::skein512_launch(d_src, bb, stride, n, g_iv512_512, d_dig, 64, s, lean); break;
+    case CW_HASH_SKEIN256_128: e = cw::skein256_launch(d_src, bb, stride, n, g_iv256_128, d_dig, 16, s, lean); break;
     case CW_HASH_SHA256: e = cw::sha256_launch(d_src, bb, stride, n, d_dig, s); break;
     case CW_HASH_NONE: return CW_OK;
     default: return fail(CW_ERR_BAD_ARG, "unknown hash algorithm %d", alg);
@@ -300,7 +300,10 @@ int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size
     HIP_TRY(hipEventRecord(t_side.fork, main_s));
     HIP_TRY(hipStreamWaitEvent(t_side.side, t_side.fork, 0));
     rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
-    if (rc == CW_OK) rc = cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, t_side.side);
+    if (rc == CW_OK) {
+        if (!d_digests) rc = fail(CW_ERR_BAD_ARG, "NULL device pointer");
+        else rc = dev_hash(hash_alg, (const uint8_t *)d_src, block_bytes, src_stride, nblocks, (uint8_t *)d_digests, t_side.side);
+    }
     HIP_TRY(hipEventRecord(t_side.join, t_side.side));
     HIP_TRY(hipStreamWaitEvent(main_s, t_side.join, 0));
     return rc;

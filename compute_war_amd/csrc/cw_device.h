@@ -18,10 +18,11 @@ struct SkeinIV { uint64_t w[8]; };
 void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv);
 
 // device launches (async on `stream`); src_stride = distance between consecutive blocks in bytes
+// lean: the caller runs codec wavefronts beside the hash kernel and wants its low-register variant
 hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean = false);
 hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean = false);
 hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *digests,
                          hipStream_t stream);
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,

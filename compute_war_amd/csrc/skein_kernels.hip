@@ -358,7 +358,7 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 
 template <int NW>
 static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean)
 {
     if (nblocks == 0) return hipSuccess;
     if ((digest_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(digests) & 15)) return hipErrorInvalidValue;
@@ -369,7 +369,15 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
                                            src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
 #define CW_LAUNCH_LINES(A) hipLaunchKernelGGL((skein_lines_kernel<NW, A>), grid, block, 0, stream, \
                                               src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
-    if (aligned && !ragged) CW_LAUNCH_LINES(true);
+    // Two hot kernels for aligned, whole-step blocks: the line kernel (123 VGPRs, every cache line fetched once) and
+    // the step kernel (92 VGPRs, 64 bytes per step, ~40 % of the lines fetched twice).  Alone they are equally fast;
+    // beside codec wavefronts the step kernel keeps 4 instead of 3 hash wavefronts per SIMD, which helped at 512 Ki
+    // blocks (32.7 vs 36-42 ms) and made no difference at 1 Mi blocks (68 vs 69 ms), so callers do not ask for it
+    // (`lean` stays false); CW_SKEIN_MODE=steps|lines overrides (profiling knob).
+    static const char *mode = getenv("CW_SKEIN_MODE");
+    const bool steps = mode ? strcmp(mode, "steps") == 0 : lean;
+    if (aligned && !ragged && steps) CW_LAUNCH(true, false);
+    else if (aligned && !ragged) CW_LAUNCH_LINES(true);
     else if (aligned) CW_LAUNCH(true, true);
     else if (!ragged) CW_LAUNCH_LINES(false);
     else CW_LAUNCH(false, true);
@@ -379,15 +387,15 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
 }
 
 hipError_t skein512_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean)
 {
-    return launch_skein<8>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream);
+    return launch_skein<8>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream, lean);
 }
 
 hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
-                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+                           uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean)
 {
-    return launch_skein<4>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream);
+    return launch_skein<4>(src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes, stream, lean);
 }
 
 // ---- host-side config-block UBI (Skein_*_Init's "no precomputed IV" path, skein.c:245-259) ----
