@@ -63,9 +63,8 @@ __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (ui
 // step = (64 + probes_so_far) >> 6 after the first two probes (LZ4_skipTrigger = 6).
 __device__ __forceinline__ uint32_t probe_delta(uint32_t k)
 {
-    if (k == 0) return 0;
     const uint32_t t = 62 + k, q = t >> 6, r = t & 63;
-    return 1 + 32 * q * (q - 1) + q * (r + 1);
+    return k ? 1 + q * (32 * (q - 1) + r + 1) : 0; // k = 0 gives q = 0 and would come out as 1
 }
 
 // wavefront copy LDS -> global, any alignment; long runs go as 16 B per lane
@@ -156,23 +155,24 @@ struct ScanState {
     uint32_t mcand = 0, mv = 0;
 };
 
-// one probe per active lane: insert (pos, v) and test it the way the parser would
-__device__ __forceinline__ void scan_probe(uint32_t *tab, uint32_t tag, uint32_t epoch, uint32_t v0, uint32_t pos, uint32_t v,
-                                           bool active, ScanState &st)
+// One probe per lane, written without branches so that the LDS operations of several batches pipeline:
+// insert (pos, v) and test it the way the parser would.  An inactive lane issues max(tab[0], 0), which can never
+// change an entry.  split: issue() returns the atomic's old word, judge() folds it into the lane's state.
+__device__ __forceinline__ uint32_t scan_issue(uint32_t *tab, uint32_t tag, uint32_t pos, uint32_t v, bool active)
 {
-    if (!active) return;
     const uint32_t h = v * 2654435761u, fp = (h >> 7) & 0xFFFu;
-    const uint32_t old = atomicMax(&tab[h >> 19], tag | (pos << 12) | fp);
-    if ((old >> 28) == epoch) {
-        const uint32_t cand = (old >> 12) & 0xFFFFu;
-        st.hit |= cand >= pos;
-        if ((old & 0xFFFu) == fp) {
-            if (st.maybe) st.hit = true; // a second one for this lane before settling: let the parser decide
-            st.maybe = true; st.mcand = cand; st.mv = v;
-        }
-    } else {
-        st.hit |= v == v0; // empty slot: the parser's candidate is position 0
-    }
+    return atomicMax(&tab[active ? h >> 19 : 0u], active ? tag | (pos << 12) | fp : 0u);
+}
+__device__ __forceinline__ void scan_judge(uint32_t old, uint32_t epoch, uint32_t v0, uint32_t pos, uint32_t v, bool active, ScanState &st)
+{
+    const uint32_t fp = ((v * 2654435761u) >> 7) & 0xFFFu, cand = (old >> 12) & 0xFFFFu;
+    const bool same = (old >> 28) == epoch;               // else: empty slot, the parser's candidate is position 0
+    const bool fpm = active && same && (old & 0xFFFu) == fp;
+    st.hit |= active && (same ? cand >= pos : v == v0);   // cand >= pos: atomics applied out of lane order
+    st.hit |= fpm && st.maybe;                            // a second fingerprint hit before settling: let the parser decide
+    st.mcand = fpm ? cand : st.mcand;
+    st.mv = fpm ? v : st.mv;
+    st.maybe |= fpm;
 }
 
 // rare: a fingerprint agreed -- settle it on the candidate's actual bytes; returns the wave-wide verdict
@@ -235,10 +235,13 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
                     const uint32_t k = k0 + 64 * j + lane;
                     pos[j] = 1 + probe_delta(k);
                     act[j] = k < nprobes;
-                    v[j] = act[j] ? ld32g(g + pos[j]) : 0;
+                    v[j] = ld32g(g + (act[j] ? pos[j] : 0u)); // unconditional: the gathers of the whole group fly together
                 }
+                uint32_t old[kScanGroup];
 #pragma unroll
-                for (int j = 0; j < kScanGroup; j++) scan_probe(tab, tag, epoch, v0, pos[j], v[j], act[j], st);
+                for (int j = 0; j < kScanGroup; j++) old[j] = scan_issue(tab, tag, pos[j], v[j], act[j]);
+#pragma unroll
+                for (int j = 0; j < kScanGroup; j++) scan_judge(old[j], epoch, v0, pos[j], v[j], act[j], st);
                 marked = scan_settle(g, st);
             }
         }
@@ -323,14 +326,18 @@ __device__ __forceinline__ void probe_upto(Walk &w, uint32_t end, uint32_t *tab,
             const uint32_t k = w.knext + 64 * j + lane;
             pos[j] = 1 + probe_delta(k);
             act[j] = k < nprobes && pos[j] < end;
-            // unaligned 4 bytes out of the ring: two aligned dwords (the second may wrap) + byte align
+            // unaligned 4 bytes out of the ring: two aligned dwords (the second may wrap) + byte align; read
+            // unconditionally (any ring address is safe) so that the reads of the whole group pipeline
             const uint32_t a0 = (pos[j] & (kRing - 1)) >> 2, a1 = (a0 + 1) & (kRing / 4 - 1);
-            v[j] = act[j] ? __builtin_amdgcn_alignbyte(ring32[a1], ring32[a0], pos[j] & 3u) : 0u;
+            v[j] = __builtin_amdgcn_alignbyte(ring32[a1], ring32[a0], pos[j] & 3u);
             nact += (uint32_t)__builtin_popcountll(__ballot(act[j]));
         }
         if (nact == 0) return;
+        uint32_t old[kStreamGroup];
 #pragma unroll
-        for (uint32_t j = 0; j < kStreamGroup; j++) scan_probe(tab, tag, epoch, w.v0, pos[j], v[j], act[j], w.st);
+        for (uint32_t j = 0; j < kStreamGroup; j++) old[j] = scan_issue(tab, tag, pos[j], v[j], act[j]);
+#pragma unroll
+        for (uint32_t j = 0; j < kStreamGroup; j++) scan_judge(old[j], epoch, w.v0, pos[j], v[j], act[j], w.st);
         w.marked = scan_settle(g, w.st);
         w.knext += nact;
         if (w.marked || nact < 64 * kStreamGroup) return;
