@@ -193,6 +193,28 @@ __device__ __forceinline__ void scan_begin_block(uint32_t *tab, uint32_t &epoch,
     }
 }
 
+// Next block for this wavefront from the shared counter (counters[2]).  Blocks are handed out dynamically because
+// the scan's workgroups become resident at different times when a hash kernel is filling the same CUs: with a
+// static partition a late workgroup still owns its full share and the kernel grows a tail.  Lane 0 pulls, the
+// index reaches the other lanes through an LDS word (see the parse kernel for why not through readfirstlane).
+// One shared word takes ~88 pulls per microsecond, so a pull hands out a run of blocks worth ~64 KiB of input.
+struct BlockFeed {
+    size_t next = 0, end = 0;
+};
+__device__ __forceinline__ bool scan_next_block(BlockFeed &f, size_t &blk, uint32_t *counters, volatile uint32_t *mailbox,
+                                                uint32_t run, size_t nblocks, uint32_t lane)
+{
+    if (f.next == f.end) {
+        __syncthreads();
+        if (lane == 0) *mailbox = atomicAdd(&counters[2], run);
+        __syncthreads();
+        f.next = __builtin_amdgcn_readfirstlane(*mailbox);
+        f.end = f.next + run;
+    }
+    blk = f.next++;
+    return blk < nblocks;
+}
+
 __device__ __forceinline__ void scan_mark(uint32_t *sizes, size_t blk, uint32_t *queue, uint32_t *counters, uint32_t lane)
 {
     if (lane == 0) {
@@ -209,11 +231,15 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
                         uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
+    __shared__ __attribute__((aligned(16))) uint32_t mailbox_word[4];
+    volatile uint32_t *mailbox = mailbox_word;
     const uint32_t lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3); // latency-bound wavefront next to ALU-bound hash wavefronts
     uint32_t epoch = 15;           // forces a clean table before the first block
 
-    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    BlockFeed feed;
+    const uint32_t run = n >= 65536 ? 1u : 65536u / n; // blocks per pull
+    for (size_t blk; scan_next_block(feed, blk, counters, mailbox, run, nblocks, lane);) {
         scan_begin_block(tab, epoch, lane);
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
@@ -351,13 +377,16 @@ lz4_scan_stream_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_s
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
     __shared__ __attribute__((aligned(16))) uint32_t ring32[kRing / 4];
+    volatile uint32_t *mailbox = ring32; // free between two blocks
     const uint32_t lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);
     uint32_t epoch = 15;
     const uint32_t nchunks = (n + kChunk - 1) / kChunk;
     const uint32_t hdr = 1 + (n >= 15 ? (n - 15) / 255 + 1 : 0); // token + length bytes of the single literal run
 
-    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    BlockFeed feed;
+    const uint32_t run = n >= 65536 ? 1u : 65536u / n; // blocks per pull
+    for (size_t blk; scan_next_block(feed, blk, counters, mailbox, run, nblocks, lane);) {
         scan_begin_block(tab, epoch, lane);
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride, *lit = out + hdr;
