@@ -704,7 +704,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // CW_LZ4_MODE=generic forces the gather-based scan (profiling knob)
     const bool streamable = ((reinterpret_cast<uintptr_t>(src) | src_stride | n) & 15) == 0 && !(mode && strcmp(mode, "generic") == 0);
     if (streamable) {
-        const size_t sgrid = nblocks < 256 * 4 ? nblocks : 256 * 4; // 40 KiB of LDS each -> 4 per CU
+        static const char *wpc_env = getenv("CW_SCAN_WPC"); // scan wavefronts per CU (profiling knob; 4 = all that fit)
+        const size_t wpc = wpc_env && atoi(wpc_env) > 0 ? (size_t)atoi(wpc_env) : 4;
+        const size_t sgrid = nblocks < 256 * wpc ? nblocks : 256 * wpc; // 40 KiB of LDS each -> at most 4 per CU
         hipLaunchKernelGGL(lz4_scan_stream_kernel, dim3((unsigned)sgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, scan_probes(n), queue, counters);
     } else {
