@@ -104,26 +104,48 @@ sha256_blocks_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     uint32_t w[16];
 
-    auto fetch = [&](uint32_t (&dst)[16], size_t step) {
-        if (step < nfull) {
-            load_chunk<ALIGNED16>(dst, p + step * 64);
-        } else if (RAGGED) {
-            load_padding(dst, p + nfull * 64, rem, (unsigned)(step - nfull), bits, two);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; i++) dst[i] = 0;
-            dst[0] = 0x80000000u; dst[14] = (uint32_t)(bits >> 32); dst[15] = (uint32_t)bits;
-        }
-    };
-
-    fetch(w, 0);
+    if (RAGGED) {
+        auto fetch = [&](uint32_t (&dst)[16], size_t step) __attribute__((always_inline)) {
+            if (step < nfull) load_chunk<ALIGNED16>(dst, p + step * 64);
+            else load_padding(dst, p + nfull * 64, rem, (unsigned)(step - nfull), bits, two);
+        };
+        fetch(w, 0);
 #pragma unroll 1
-    for (size_t step = 0; step < nsteps; step++) {
-        uint32_t nx[16];
-        if (step + 1 < nsteps) fetch(nx, step + 1); // next chunk's loads fly under this chunk's 64 rounds
-        sha256_compress(h, w);
+        for (size_t step = 0; step < nsteps; step++) {
+            uint32_t nx[16];
+            if (step + 1 < nsteps) fetch(nx, step + 1);
+            sha256_compress(h, w);
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = nx[i];
+            for (int i = 0; i < 16; i++) w[i] = nx[i];
+        }
+    } else {
+        // Hot path.  The next chunk's loads are issued unconditionally (the padding step re-reads the last chunk and
+        // is replaced) and are only touched AFTER this chunk's 64 rounds: a branch around the loads, or a byte swap
+        // right behind them, makes hipcc put s_waitcnt vmcnt(0) in front of the rounds and nothing overlaps.
+        load_chunk<ALIGNED16>(w, p);
+#pragma unroll 1
+        for (size_t step = 0; step < nsteps; step++) {
+            const size_t nxt = step + 1;
+            const bool msg = nxt < nfull; // wave-uniform
+            const uint8_t *q = p + (msg ? nxt : nfull - 1) * 64;
+            uint32_t raw[16];
+            if (ALIGNED16) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(q)[i];
+                    raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+                }
+            } else {
+                load_chunk<false>(raw, q);
+            }
+            sha256_compress(h, w);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t v = ALIGNED16 ? __builtin_bswap32(raw[i]) : raw[i];
+                const uint32_t pad = i == 0 ? 0x80000000u : i == 14 ? (uint32_t)(bits >> 32) : i == 15 ? (uint32_t)bits : 0u;
+                w[i] = msg ? v : pad;
+            }
+        }
     }
 
     uint4 *out = reinterpret_cast<uint4 *>(digests + gid * 32);

@@ -231,10 +231,18 @@ skein_blocks_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t 
 #pragma unroll 1
     for (size_t step = 0; step < nsteps; step++) {
         uint64_t nx[NW];
-        // issue the NEXT step's message loads before this step's 72 rounds
-        if (step + 1 < nfull || (step + 1 == nfull && rem == BB)) {
+        // issue the NEXT step's message loads before this step's 72 rounds.  In the hot (!RAGGED) instantiation the
+        // load is unconditional -- past the message it re-reads the last step and is masked to zero -- because hipcc
+        // answers loads inside a branch with a vmcnt(0) right behind them, which would serialise fetch and rounds.
+        if (!RAGGED) {
+            const size_t nxt_step = step + 1;
+            const uint64_t keep = nxt_step <= nfull ? ~0ull : 0ull; // steps 0..nfull carry message bytes
+            load_words<NW, ALIGNED16>(nx, p + (nxt_step <= nfull ? nxt_step : nfull) * BB);
+#pragma unroll
+            for (int k = 0; k < NW; k++) nx[k] &= keep;
+        } else if (step + 1 < nfull || (step + 1 == nfull && rem == BB)) {
             load_words<NW, ALIGNED16>(nx, p + (step + 1) * BB);
-        } else if (RAGGED && step + 1 == nfull) {
+        } else if (step + 1 == nfull) {
             load_tail<NW>(nx, p + (step + 1) * BB, rem);
         } else {
 #pragma unroll
@@ -297,17 +305,18 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     uint64_t t0 = 0, t1 = T1_FIRST | T1_MSG;
 
     uint64_t A[HS][NW], B[HS][NW], S[HS][NW];
-    // steps [first, first+HS) of the message into one half-line buffer; steps past the message read as zero
-    auto fetch_half = [&](uint64_t (&dst)[HS][NW], size_t first) {
+    // steps [first, first+HS) of the message into one half-line buffer; steps past the message read as zero.
+    // The loads are UNCONDITIONAL (a step past the message re-reads the last step and is masked to zero): with the
+    // loads inside a branch hipcc cannot count how many are outstanding and waits for all of them (vmcnt(0)) right
+    // at the top of the loop, i.e. the prefetch would not overlap the rounds at all.
+    auto fetch_half = [&](uint64_t (&dst)[HS][NW], size_t first) __attribute__((always_inline)) {
 #pragma unroll
         for (unsigned j = 0; j < HS; j++) {
             const size_t s = first + j;
-            if (s < nmsg) {
-                load_words<NW, ALIGNED16>(dst[j], p + s * BB);
-            } else {
+            const uint64_t keep = s < nmsg ? ~0ull : 0ull; // wave-uniform
+            load_words<NW, ALIGNED16>(dst[j], p + (s < nmsg ? s : nmsg - 1) * BB);
 #pragma unroll
-                for (int k = 0; k < NW; k++) dst[j][k] = 0;
-            }
+            for (int k = 0; k < NW; k++) dst[j][k] &= keep;
         }
     };
     auto run_half = [&](uint64_t (&buf)[HS][NW], size_t first) {
@@ -369,7 +378,7 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
                                            src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
 #define CW_LAUNCH_LINES(A) hipLaunchKernelGGL((skein_lines_kernel<NW, A>), grid, block, 0, stream, \
                                               src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
-    // Two hot kernels for aligned, whole-step blocks: the line kernel (123 VGPRs, every cache line fetched once) and
+    // Two hot kernels for aligned, whole-step blocks: the line kernel (105 VGPRs, every cache line fetched once) and
     // the step kernel (92 VGPRs, 64 bytes per step, ~40 % of the lines fetched twice).  Alone they are equally fast;
     // beside codec wavefronts the step kernel keeps 4 instead of 3 hash wavefronts per SIMD, which helped at 512 Ki
     // blocks (32.7 vs 36-42 ms) and made no difference at 1 Mi blocks (68 vs 69 ms), so callers do not ask for it
