@@ -437,6 +437,42 @@ int cw_compress_blocks(int comp_alg, const void *src, size_t block_bytes, size_t
     return cw_hash_and_compress_blocks(CW_HASH_NONE, comp_alg, src, block_bytes, nblocks, nullptr, dst, dst_stride, sizes);
 }
 
+int cw_decompress_blocks(int comp_alg, const void *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, void *dst,
+                         size_t block_bytes, uint32_t *status)
+{
+    ThreadCtx &c = t_ctx;
+    int rc = c.open();
+    if (rc != CW_OK) return rc;
+    if (nblocks == 0) return CW_OK;
+    if (!comp || !sizes || !dst || !status) return fail(CW_ERR_BAD_ARG, "NULL pointer");
+    if (comp_alg != CW_COMP_LZ4 && comp_alg != CW_COMP_LZF) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
+    if (block_bytes == 0 || (rc = check_block(block_bytes)) != CW_OK) return rc ? rc : fail(CW_ERR_BAD_ARG, "block_bytes == 0");
+    const size_t d_stride = (comp_stride + 15) & ~(size_t)15;
+    size_t chunk = kMaxChunkBytes / (d_stride + block_bytes + 8);
+    if (chunk == 0) chunk = 1;
+    if (chunk > nblocks) chunk = nblocks;
+    if ((rc = c.src.reserve(chunk * d_stride + 16)) != CW_OK || (rc = c.dst.reserve(chunk * block_bytes)) != CW_OK ||
+        (rc = c.sizes.reserve(chunk * 4)) != CW_OK || (rc = c.dig.reserve(chunk * 4)) != CW_OK)
+        return rc;
+    for (size_t first = 0; first < nblocks; first += chunk) {
+        const size_t n = nblocks - first < chunk ? nblocks - first : chunk;
+        for (size_t i = 0; i < n; i++) { // only the bytes each slot holds cross the bus
+            const uint32_t sz = sizes[first + i];
+            if (sz > comp_stride) return fail(CW_ERR_BAD_ARG, "block %zu: %u bytes exceed comp_stride %zu", first + i, sz, comp_stride);
+            if (sz) HIP_TRY(hipMemcpyAsync((uint8_t *)c.src.p + i * d_stride, (const uint8_t *)comp + (first + i) * comp_stride, sz,
+                                           hipMemcpyHostToDevice, c.stream));
+        }
+        HIP_TRY(hipMemcpyAsync(c.sizes.p, sizes + first, n * 4, hipMemcpyHostToDevice, c.stream));
+        rc = cw_dev_decompress(comp_alg, c.src.p, d_stride, (const uint32_t *)c.sizes.p, n, c.dst.p, block_bytes, (uint32_t *)c.dig.p,
+                               c.stream);
+        if (rc != CW_OK) return rc;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)dst + first * block_bytes, c.dst.p, n * block_bytes, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(status + first, c.dig.p, n * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+    }
+    return CW_OK;
+}
+
 // ---- the reference's slots ----------------------------------------------------------------------------------
 void cw_hash_skein(const char *src, char *dst, int count)
 {
@@ -470,6 +506,24 @@ size_t cw_compress_lzf(const char *src, char *dst, size_t len)
     if (len < 2) return 0; // lzf_compress(in, len, out, len-1) cannot fit anything
     if (cw_compress_blocks(CW_COMP_LZF, src, len, 1, dst, len - 1, &sz) != CW_OK) die("cw_compress_lzf");
     return sz;
+}
+
+int cw_decompress_lz4(const char *src, char *dst, int csize, int dst_cap)
+{
+    const size_t bb = cw_get_block_size();
+    uint32_t sz = csize > 0 ? (uint32_t)csize : 0, st = 1;
+    if (csize <= 0 || dst_cap < 0 || (size_t)dst_cap < bb) return -1;
+    if (cw_decompress_blocks(CW_COMP_LZ4, src, sz, &sz, 1, dst, bb, &st) != CW_OK) die("cw_decompress_lz4");
+    return st == 0 ? (int)bb : -1;
+}
+
+unsigned cw_decompress_lzf(const void *src, unsigned csize, void *dst, unsigned dst_cap)
+{
+    const size_t bb = cw_get_block_size();
+    uint32_t sz = csize, st = 1;
+    if (csize == 0 || dst_cap < bb) return 0;
+    if (cw_decompress_blocks(CW_COMP_LZF, src, sz, &sz, 1, dst, bb, &st) != CW_OK) die("cw_decompress_lzf");
+    return st == 0 ? (unsigned)bb : 0;
 }
 
 // ---- HashOffload -------------------------------------------------------------------------------------------------

@@ -102,6 +102,29 @@ def compress_blocks(alg, src, block_bytes: int):
     return sizes, payload
 
 
+def decompress_blocks(alg, sizes, payload, block_bytes: int):
+    """Inverse of compress_blocks: (blocks[n, block_bytes] uint8, status[n] uint32; 0 = ok)."""
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    n, stride = payload.shape
+    out = np.zeros((n, block_bytes), dtype=np.uint8)
+    status = np.ones(n, dtype=np.uint32)
+    check(lib().cw_decompress_blocks(_comp_id(alg), payload.ctypes.data, stride, sizes.ctypes.data, n, out.ctypes.data,
+                                     block_bytes, status.ctypes.data))
+    return out, status
+
+
+def do_decompression(alg, comp: bytes, cap: int) -> bytes:
+    """LZ4_decompress_safe / lzf_decompress slot (experiment.cpp:118,256): b"" on a malformed slot."""
+    src = np.frombuffer(comp, dtype=np.uint8)
+    dst = np.zeros(cap, dtype=np.uint8)
+    if _comp_id(alg) == 0:
+        n = lib().cw_decompress_lz4(src.ctypes.data, dst.ctypes.data, len(comp), cap)
+    else:
+        n = lib().cw_decompress_lzf(src.ctypes.data, len(comp), dst.ctypes.data, cap)
+    return dst[:n].tobytes() if n > 0 else b""
+
+
 def hash_and_compress_blocks(hash_alg, comp_alg, src, block_bytes: int):
     """ProcessBlock (:231-261) over every block of `src`: (digests, sizes, payload)."""
     a = _np_u8(src)

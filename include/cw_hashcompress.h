@@ -84,6 +84,13 @@ void   cw_hash_skein512(const char *src, char *dst, int count);   /* Skein-512-5
 void   cw_hash_sha256mb(const char *src, char *dst, int count);   /* doSHA256MBHashing (digests ARE returned) */
 size_t cw_compress_lz4(const char *src, char *dst, size_t len);
 size_t cw_compress_lzf(const char *src, char *dst, size_t len);
+/* The decoders the reference times beside the compressors (src/compression_perf/src/experiment.cpp:118,256):
+ *   int LZ4_decompress_safe(src, dst, csize, dst_cap)           -> decoded bytes, < 0 = malformed
+ *   unsigned lzf_decompress(src, csize, dst, dst_cap)           -> decoded bytes, 0 = error (lzf.h:83-97)
+ * One difference: the device decoder is told the decoded size, so a slot must decode to exactly
+ * cw_get_block_size() bytes (what every caller in the reference expects); anything else is "malformed". */
+int      cw_decompress_lz4(const char *src, char *dst, int csize, int dst_cap);
+unsigned cw_decompress_lzf(const void *src, unsigned csize, void *dst, unsigned dst_cap);
 
 /* ---- batched host API: many blocks per call (H2D, kernels, D2H on the caller's stream) --------
  * src: nblocks * block_bytes contiguous; digests: nblocks * cw_digest_bytes(); dst: nblocks slots of
@@ -96,6 +103,10 @@ int cw_compress_blocks(int comp_alg, const void *src, size_t block_bytes, size_t
 int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, size_t block_bytes,
                                 size_t nblocks, void *digests, void *dst, size_t dst_stride,
                                 uint32_t *sizes);
+/* decode nblocks slots (comp_stride apart, sizes[i] bytes each) into nblocks * block_bytes at dst;
+ * status[i] = 0 iff slot i is well formed and yields exactly block_bytes (see cw_dev_decompress).  */
+int cw_decompress_blocks(int comp_alg, const void *comp, size_t comp_stride, const uint32_t *sizes,
+                         size_t nblocks, void *dst, size_t block_bytes, uint32_t *status);
 
 /* ---- device-resident API: every pointer is device memory, work is queued on `stream`
  *      (a hipStream_t passed as void*; NULL = the default stream) and NOT synchronised -----------

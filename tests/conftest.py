@@ -45,6 +45,17 @@ def corpus_names():
     return sorted(os.listdir(os.path.join(GOLDEN, "corpus", "canterbury")))
 
 
+def corpus_large_names():
+    return sorted(f[:-3] for f in os.listdir(os.path.join(GOLDEN, "corpus", "canterbury-large")) if f.endswith(".xz"))
+
+
+def corpus_large_file(name):
+    """dataset/canterbury-large of the reference (bible.txt, world192.txt), committed xz-compressed (6.3 MB raw)."""
+    import lzma
+    with lzma.open(os.path.join(GOLDEN, "corpus", "canterbury-large", name + ".xz"), "rb") as f:
+        return f.read()
+
+
 def anchor_input(kind, n):
     if kind == "alice29":
         return corpus_file("alice29.txt")[:n]

@@ -72,3 +72,39 @@ def test_hashing_perf_log_format(tmp_path):
     assert [l.split("|")[1] for l in sb] == [str(i) for i in range(10)]
     assert len(mb) == sum(5 // w for w in range(1, 65))    # windows 1..64 (test.cpp:87-90)
     assert all(re.fullmatch(r".+\|\d+\|Sha256MB\|\d+\|\d+\|", l) for l in mb)
+
+
+COMP_PERF = os.path.join(ROOT, "compute_war_amd", "host", "compression_perf")
+
+
+@pytest.mark.parametrize("mode", [[], ["--batch"]])
+def test_compression_perf_lines_match_oracle(oracle, tmp_path, mode):
+    """N3: alg|csize|comp_us|decomp_us|file|block for every full 4 KiB block (experiment.cpp:105-125,243-267)."""
+    d = tmp_path / "data"
+    d.mkdir()
+    files = {"a.txt": corpus_file("alice29.txt")[:7 * 4096 + 5], "b.bin": os.urandom(2 * 4096), "c.xls": corpus_file("kennedy.xls")[:3 * 4096]}
+    for k, v in files.items():
+        (d / k).write_bytes(v)
+    r = subprocess.run([COMP_PERF, "-f", "-4"] + mode + [str(d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = [l.split("|") for l in r.stdout.strip().splitlines()]
+    want = []
+    for name in sorted(files):
+        data = files[name]
+        for i in range(len(data) // 4096):
+            b = data[i * 4096:(i + 1) * 4096]
+            want.append(("lzf", len(oracle.lzf_compress(b)), str(d / name), i + 1))
+            want.append(("lz4", len(oracle.lz4_compress(b)), str(d / name), i + 1))
+    assert [(g[0], int(g[1]), g[4], int(g[5])) for g in got] == want
+    assert all(g[2].isdigit() and g[3].isdigit() and len(g) == 6 for g in got)
+    # --best: one line per block, lz4 only when strictly smaller than lzf's result (experiment.cpp:115,261,507)
+    r = subprocess.run([COMP_PERF, "-f", "-4", "-B"] + mode + [str(d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    best = [l.split("|") for l in r.stdout.strip().splitlines()]
+    exp = [(f if f[1] <= z[1] else z) for f, z in zip(want[0::2], want[1::2])]
+    assert [(g[0], int(g[1]), g[4], int(g[5])) for g in best] == exp
+
+
+def test_compression_perf_refuses_other_codecs():
+    r = subprocess.run([COMP_PERF, "--gzip", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "not part of this build" in r.stderr

@@ -5,7 +5,8 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import anchor_input, corpus_file, corpus_names, load_golden, seeded_block
+from conftest import (anchor_input, corpus_file, corpus_large_file, corpus_large_names, corpus_names, load_golden,
+                      seeded_block)
 
 pytestmark = pytest.mark.gpu
 
@@ -228,6 +229,43 @@ def test_sha256_lzf_pipeline(cw, oracle):
         assert dig[i].tobytes() == hashlib.sha256(b).digest()
         want = oracle.lzf_compress(b)
         assert sizes[i] == len(want) and payload[i, :sizes[i]].tobytes() == want
+
+
+def _large_corpus_blocks(bs):
+    data = b"".join(d[:len(d) // 65536 * 65536] for d in (corpus_large_file(n) for n in corpus_large_names()))
+    return data, len(data) // bs
+
+
+@pytest.mark.parametrize("bs", [4096, 65536])
+def test_config3_sha256_lzf_over_canterbury_large(cw, oracle, bs):
+    """BASELINE.json configs[3]: SHA-256 + LZF (hc_shlzf) over dataset/canterbury-large; every block bit-exact, corpus
+    ratio = the reference's."""
+    data, nb = _large_corpus_blocks(bs)
+    dig, sizes, payload = cw.hash_and_compress_blocks("sha256mb", "lzf", data, bs)
+    for i in range(nb):
+        b = data[i * bs:(i + 1) * bs]
+        assert dig[i].tobytes() == hashlib.sha256(b).digest()
+        want = oracle.lzf_compress(b)
+        assert sizes[i] == len(want) and payload[i, :sizes[i]].tobytes() == want, (bs, i)
+    want = next(r for r in load_golden("survey_anchors.json")["corpus_ratios"]
+                if r["corpus"] == "canterbury-large" and r["block"] == bs)
+    assert round(len(data) / int(np.where(sizes == 0, bs, sizes).sum()), 4) == want["lzf"]
+
+
+@pytest.mark.parametrize("bs", [4096, 65536])
+def test_config2_skein512_lz4_over_corpus_chunks(cw, oracle, bs):
+    """BASELINE.json configs[2] (fused Skein-512 + LZ4 over a corpus chunked at 64 KiB).  Silesia is not in the
+    reference tree, so the in-tree large corpus stands in; 4 KiB is the reference driver's own block size."""
+    data, nb = _large_corpus_blocks(bs)
+    dig, sizes, payload = cw.hash_and_compress_blocks("skein512", "lz4", data, bs)
+    for i in range(nb):
+        b = data[i * bs:(i + 1) * bs]
+        assert dig[i].tobytes() == oracle.skein512(b, 512)
+        want = oracle.lz4_compress(b)
+        assert sizes[i] == len(want) and payload[i, :sizes[i]].tobytes() == want, (bs, i)
+    want = next(r for r in load_golden("survey_anchors.json")["corpus_ratios"]
+                if r["corpus"] == "canterbury-large" and r["block"] == bs)
+    assert round(len(data) / int(sizes.sum()), 4) == want["lz4"]
 
 
 # ---------------------------------------------------------------- device API, fused, offload

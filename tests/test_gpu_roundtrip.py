@@ -78,3 +78,24 @@ def test_decoders_accept_oracle_streams_and_reject_garbage(cw, oracle):
         assert list(st[:len(blocks)]) == [0] * len(blocks) and list(st[-2:]) == [1, 1]
         for i, b in enumerate(blocks):
             assert hb[i].tobytes() == b
+
+
+@pytest.mark.parametrize("alg", ["lz4", "lzf"])
+def test_host_decompress_blocks_and_slots(alg):
+    """cw_decompress_blocks / cw_decompress_lz4 / cw_decompress_lzf invert the compressors (host buffers)."""
+    import compute_war_amd as cw
+    cw.init(0)
+    bs = 4096
+    data = (corpus_file("lcet10.txt")[:40 * bs] + bytes(bs) + corpus_file("ptt5")[:23 * bs])
+    sizes, payload = cw.compress_blocks(alg, data, bs)
+    out, status = cw.decompress_blocks(alg, sizes, payload, bs)
+    for i in range(len(data) // bs):
+        if sizes[i] == 0:      # lzf: did not fit
+            continue
+        assert status[i] == 0 and out[i].tobytes() == data[i * bs:(i + 1) * bs]
+    cw.set_block_size(bs)
+    blk = data[3 * bs:4 * bs]
+    comp = payload[3, :sizes[3]].tobytes()
+    assert cw.do_decompression(alg, comp, 2 * bs) == blk
+    assert cw.do_decompression(alg, comp[:-3], 2 * bs) == b""          # truncated slot = malformed
+    assert cw.do_decompression(alg, comp, bs - 1) == b""               # capacity below the block size

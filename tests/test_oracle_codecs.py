@@ -8,7 +8,8 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import anchor_input, corpus_file, corpus_names, load_golden, seeded_block
+from conftest import (anchor_input, corpus_file, corpus_large_file, corpus_large_names, corpus_names, load_golden,
+                      seeded_block)
 
 
 def test_survey_anchor_sizes_and_digests(oracle):
@@ -42,6 +43,28 @@ def test_canterbury_ratios(oracle, bs):
     assert round(tin / tf, 4) == want["lzf"]
     tot = next(t for t in load_golden("codec_regress.json")["totals"]
                if t["corpus"] == "canterbury" and t["block"] == bs)
+    assert (tin, t4, tf) == (tot["in"], tot["lz4"], tot["lzf"])
+
+
+@pytest.mark.parametrize("bs", [4096, 65536])
+def test_canterbury_large_ratios(oracle, bs):
+    """dataset/canterbury-large (BASELINE.json configs[3]): corpus ratios of SURVEY.md 8(d) [liblz4.a / liblzf.a probe]."""
+    want = next(r for r in load_golden("survey_anchors.json")["corpus_ratios"]
+                if r["corpus"] == "canterbury-large" and r["block"] == bs)
+    tin = t4 = tf = 0
+    for name in corpus_large_names():
+        data = corpus_large_file(name)
+        whole = len(data) // 65536 * 65536
+        for o in range(0, whole, bs):
+            b = data[o:o + bs]
+            c4, cf = oracle.lz4_compress(b), oracle.lzf_compress(b)
+            tin += bs
+            t4 += len(c4)
+            tf += len(cf) if cf else bs
+    assert round(tin / t4, 4) == want["lz4"]
+    assert round(tin / tf, 4) == want["lzf"]
+    tot = next(t for t in load_golden("codec_regress.json")["totals"]
+               if t["corpus"] == "canterbury-large" and t["block"] == bs)
     assert (tin, t4, tf) == (tot["in"], tot["lz4"], tot["lzf"])
 
 
