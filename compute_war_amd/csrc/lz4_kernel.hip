@@ -56,6 +56,19 @@ __device__ __forceinline__ uint32_t rd32(const uint8_t *lds, uint32_t pos)
     __builtin_memcpy(&v, lds + pos, 4); // unaligned ds_read_b32
     return v;
 }
+// 4 bytes at any offset of a block staged in LDS.  An unaligned ds_read is legal but the LDS handles it lane by lane
+// (SQ_LDS_UNALIGNED_STALL was 92 % of the LDS-busy cycles of the parse kernel, which it saturated), so: the two
+// aligned dwords around the position (one ds_read2_b32) and a byte align; callers keep pos <= n - 8, so the second
+// dword is inside the staged bytes.  Blocks read from global memory use plain unaligned loads.
+template <bool STAGED>
+__device__ __forceinline__ uint32_t rd32x(const uint8_t *in, uint32_t pos)
+{
+    if (STAGED) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (pos >> 2);
+        return __builtin_amdgcn_alignbyte(w[1], w[0], pos & 3u);
+    }
+    return rd32(in, pos);
+}
 __device__ __forceinline__ uint32_t hash13(uint32_t v) { return (v * 2654435761u) >> 19; }
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 
@@ -537,7 +550,7 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
 
                     uint32_t v = 0, h = 0, old = 0;
                     if (active) {
-                        v = rd32(in, pos);
+                        v = rd32x<STAGED>(in, pos);
                         h = hash13(v);
                         old = tab[h];
                         tab[h] = (uint16_t)pos;
@@ -551,7 +564,7 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
                     if (m == fa) m = fa + 1; // the first active lane read the table before any write of this batch
                     const uint32_t L = m < ndead ? m : ndead;
 
-                    const bool eq = active && t != 0 && lane < L && rd32(in, old) == v;
+                    const bool eq = active && t != 0 && lane < L && rd32x<STAGED>(in, old) == v;
                     const unsigned long long eqmask = __ballot(eq);
                     const uint32_t ncommit = eqmask ? ctz64(eqmask) + 1 : L;
                     // undo speculative writes beyond the committed lanes, then re-assert the committed ones
@@ -653,13 +666,256 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
     }
 }
 
-// per-stream workspace: counters[2] (queue head, tail) followed by the queue of block indices
+// ---------------------------------------------------------------------------------------------------
+// Parse kernel, second generation: the same item list per sequence, but the table operation of a batch is ONE
+// LDS instruction -- ds_mskor_rtn_b32, a masked exchange of the slot's 16 bits inside its 32-bit word that returns
+// the previous content.  The LDS applies the lanes of one such instruction in ascending lane order, so a lane gets
+// back exactly what the serial parser would have read at its item, INCLUDING the writes of earlier lanes of the
+// same batch: no write/read-back round, no cutting of batches at colliding lanes, one batch per sequence.  That
+// order is measured (tools/mskor_order.hip: 0 of 1.5 M same-slot successors out of order) but not architecturally
+// promised, so it is checked on every batch: any other order hands some lane a candidate >= its own position,
+// which the serial parser can never see, and such a block is requeued for lz4_blocks_kernel above, which does not
+// depend on it.  Speculative writes of the lanes behind the first match are undone by the first lane of each
+// slot's group (its returned value is the slot's content before the group).
+// Round trips per sequence: (1) the 4 bytes at every item of the next batch -- requested as soon as the match end
+// is known, before the sequence is emitted; they also ARE the next literals, which are stored from registers;
+// (2) the table exchange; (3) the candidates' 4 bytes together with 8 bytes after / 4 bytes before both the
+// position and the candidate, so that matches up to 11 bytes and catch-ups up to 3 bytes (most of them) need no
+// further round.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tab_exchange(uint32_t tab_lds, uint32_t h, uint32_t pos)
+{
+    const uint32_t addr = tab_lds + (h >> 1) * 4, sh = (h & 1) * 16;
+    uint32_t old;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(old) : "v"(addr), "v"(0xFFFFu << sh), "v"(pos << sh) : "memory");
+    return (old >> sh) & 0xFFFFu;
+}
+// the 16 bytes around a position: [p-4, p) (only if has_before), [p, p+4), [p+4, p+12)
+struct Around { uint32_t before, at; uint64_t after; };
+template <bool STAGED>
+__device__ __forceinline__ Around around(const uint8_t *in, uint32_t p, bool has_before)
+{
+    Around a;
+    if (STAGED) { // five aligned dwords from p-4 on; never a dword outside the staged bytes (no padding: 8 blocks of 4 KiB per CU)
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (p >> 2);
+        const uint32_t sh = p & 3u;
+        const uint32_t w0 = w[has_before ? -1 : 0], w1 = w[0], w2 = w[1], w3 = w[2], w4 = w[sh ? 3 : 2]; // p <= n - 12
+        a.before = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        a.at = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        a.after = __builtin_amdgcn_alignbyte(w3, w2, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32);
+    } else {
+        a.before = rd32(in, has_before ? p - 4 : 0u);
+        a.at = rd32(in, p);
+        __builtin_memcpy(&a.after, in + p + 4, 8);
+    }
+    return a;
+}
+
+template <bool STAGED>
+__global__ void __launch_bounds__(64)
+lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
+                 uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes,
+                 const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t *__restrict__ requeue)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+    uint8_t *lds_in = smem + kTabBytes;
+    const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(tab); // LDS byte address of the table
+    const uint32_t lane = threadIdx.x;
+
+    const uint32_t qcount = counters[1];
+    volatile uint32_t *mailbox = reinterpret_cast<volatile uint32_t *>(tab);
+    for (uint32_t guard = 0; guard <= qcount; guard++) {
+        __syncthreads();
+        if (lane == 0) *mailbox = atomicAdd(&counters[0], 1u);
+        __syncthreads();
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(*mailbox);
+        if (qi >= qcount) break;
+        const size_t blk = queue[qi];
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+
+        __syncthreads();
+        const uint8_t *in = STAGED ? lds_in : g;
+        if (STAGED) {
+            if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+                const uint4 *g4 = reinterpret_cast<const uint4 *>(g);
+                const uint32_t nvec = n >> 4;
+                for (uint32_t i = lane; i < nvec; i += 64) reinterpret_cast<uint4 *>(lds_in)[i] = g4[i];
+                for (uint32_t i = (nvec << 4) + lane; i < n; i += 64) lds_in[i] = g[i];
+            } else {
+                for (uint32_t i = lane; i < n; i += 64) lds_in[i] = g[i];
+            }
+        }
+        for (uint32_t i = lane; i < kTabBytes / 16; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+
+        uint32_t anchor = 0, op = 0;
+        bool broken = false; // lane-order check failed (or an impossible state): hand the block to the other parser
+
+        if (n >= kMFLimit + 1) {
+            const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
+            // head batch of a search: lane 0 inserts `ins`, lane 1 re-tests s0-1 (= ip, after a match), lane t >= 2
+            // probes s0 + t - 2 (the first 65 probes advance by 1); the literals of the sequence start at s0-1,
+            // so literal i is the low byte of lane i+1's value
+            uint32_t ins = 0, s0 = 1;
+            bool has_retest = false;
+            auto head_pos = [&](uint32_t ins_, uint32_t s0_) { return lane == 0 ? ins_ : s0_ - 2 + lane; };
+            uint32_t vhead;
+            {
+                const uint32_t p = head_pos(ins, s0);
+                vhead = rd32x<STAGED>(in, p <= n - 8 ? p : n - 8); // only positions <= n - 12 are ever used
+            }
+
+            for (uint32_t seq = 0; seq < n; seq++) {
+                uint32_t mpos = 0, match = 0, mc = 0, back = 0;
+                bool found = false, flong = false, blong = false;
+                for (uint32_t t0 = 0;; t0 += 64) {
+                    const uint32_t t = t0 + lane, k = t - 2;
+                    const bool is_probe = t >= 2;
+                    const uint32_t dk = t0 == 0 ? k : probe_delta(k), stepk = k == 0 ? 1u : (63u + k) >> 6;
+                    const uint32_t pos = t == 0 ? ins : t == 1 ? s0 - 1 : s0 + dk;
+                    const bool dead = is_probe && s0 + dk + stepk > mflimit + 1;
+                    const bool active = !dead && (is_probe || t == 0 || has_retest);
+                    const unsigned long long amask = __ballot(active);
+                    if (!amask) break;
+
+                    uint32_t v = vhead;
+                    if (t0 != 0) v = rd32x<STAGED>(in, active ? pos : 0u);
+                    const uint32_t h = hash13(v);
+                    uint32_t old = 0;
+                    if (active) old = tab_exchange(tab_lds, h, pos);
+                    const bool tested = active && t != 0;
+                    if (__ballot(tested && old >= pos)) { broken = true; break; }
+
+                    // candidate bytes, and the neighbourhood that settles short extensions in the same round
+                    const bool near_start = pos < 4 || old < 4;
+                    Around ap, ac;
+                    ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 0; ac.after = 1;
+                    if (tested) {
+                        ac = around<STAGED>(in, old, !near_start);
+                        ap = around<STAGED>(in, pos, !near_start); // pos <= n - 12
+                    }
+                    const uint32_t c4 = ac.at, b_a = ap.before, b_b = ac.before;
+                    const uint64_t f_a = ap.after, f_b = ac.after;
+                    const bool eq = tested && c4 == v;
+                    const unsigned long long eqmask = __ballot(eq);
+                    if (eqmask) {
+                        const uint32_t w = ctz64(eqmask);
+                        const uint32_t pm = __builtin_amdgcn_readlane(pos | (old << 16), w);
+                        mpos = pm & 0xFFFFu; match = pm >> 16;
+                        // undo the speculative writes behind the match: the first lane of each slot's group got the
+                        // content from before the group (a value <= mpos); later lanes of a group got a position > mpos
+                        if (active && lane > w && old <= mpos) tab[h] = (uint16_t)old;
+                        // forward: bytes 4..11; backward: up to 3 (4 = keep going)
+                        const uint64_t x = f_a ^ f_b;
+                        uint32_t nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                        const uint32_t lim = matchlimit - (pos + 4);
+                        bool fl = false;
+                        if (nf >= lim) nf = lim; else fl = nf == 8;
+                        const uint32_t room = pos - anchor < old ? pos - anchor : old; // bytes the match may move back
+                        const uint32_t y = b_a ^ b_b;
+                        uint32_t nb = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+                        bool bl = false;
+                        if (near_start) { nb = 0; bl = room != 0; }
+                        else if (nb >= room) nb = room;
+                        else bl = nb == 4;
+                        const uint32_t packed = __builtin_amdgcn_readlane(nf | (nb << 8) | ((uint32_t)fl << 16) | ((uint32_t)bl << 17), w);
+                        mc = packed & 0xFFu; back = (packed >> 8) & 0xFFu;
+                        flong = (packed >> 16) & 1u; blong = (packed >> 17) & 1u;
+                        found = true;
+                        break;
+                    }
+                    if (__ballot(dead)) break; // the next probe would pass the end of the block
+                }
+                if (broken || !found) break;
+
+                if (flong) { // long match: keep counting, 64 bytes per round
+                    for (;;) {
+                        const uint32_t i = mpos + kMinMatch + mc + lane;
+                        const bool ok = i < matchlimit && in[i] == in[match + kMinMatch + mc + lane];
+                        const uint32_t cnt = ctz64(~__ballot(ok));
+                        mc += cnt;
+                        if (cnt < 64) break;
+                    }
+                }
+                if (blong) { // long catch-up (rare)
+                    for (;;) {
+                        const uint32_t j = back + lane + 1;
+                        const bool ok = mpos >= anchor + j && match >= j && in[mpos - j] == in[match - j];
+                        const uint32_t cnt = ctz64(~__ballot(ok));
+                        back += cnt;
+                        if (cnt < 64) break;
+                    }
+                }
+                const uint32_t mend = mpos + kMinMatch + mc; // first byte after the match
+                const uint32_t ip = mpos - back;
+                match -= back; mc += back;                   // LZ4_count restarts 4 bytes after the moved-back start
+                if (ip < anchor || mend > n) { broken = true; break; } // cannot happen; never write out of bounds
+
+                // request the next search's head values now; the stores below do not wait for them
+                const uint32_t lit_v = vhead;
+                const bool more = mend <= mflimit;
+                if (more) {
+                    const uint32_t p = head_pos(mend - 2, mend + 1);
+                    vhead = rd32x<STAGED>(in, p <= n - 8 ? p : n - 8); // only positions <= n - 12 are ever used
+                }
+
+                // ---- emit: literals [anchor, ip), offset, match length ----
+                const uint32_t lit = ip - anchor, tok_pos = op;
+                uint32_t token;
+                op += 1;
+                if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
+                else token = lit << 4;
+                if (lane >= 1 && lane <= lit) out[op + lane - 1] = (uint8_t)lit_v; // literal i sits in lane i+1
+                if (lit > 63) copy_out(out + op + 63, in, anchor + 63, lit - 63, lane);
+                op += lit;
+                const uint32_t off = ip - match, off_pos = op;
+                op += 2;
+                if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
+                else token += mc;
+                if (lane < 3) { // token and the two offset bytes: three lanes, one store instruction
+                    const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
+                    const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
+                    out[where] = (uint8_t)what;
+                }
+
+                anchor = mend;
+                if (!more) break; // end of parse: remaining bytes are literals
+                ins = mend - 2; s0 = mend + 1; has_retest = true;
+            }
+        }
+        if (broken) {
+            if (lane == 0) requeue[atomicAdd(&counters[5], 1u)] = (uint32_t)blk; // counters[4..5]: second queue head, tail
+            continue;
+        }
+
+        // ---- last literals ----
+        {
+            const uint32_t run = n - anchor;
+            const uint32_t tok_pos = op;
+            op += 1;
+            if (run >= 15) {
+                if (lane == 0) out[tok_pos] = 15u << 4;
+                op += put_len(out + op, run - 15, lane);
+            } else if (lane == 0) {
+                out[tok_pos] = (uint8_t)(run << 4);
+            }
+            copy_out(out + op, in, anchor, run, lane);
+            op += run;
+        }
+        if (lane == 0) sizes[blk] = op;
+    }
+}
+
+// per-stream workspace: counters[8] (parse queue head, tail; scan feed; -; second queue head, tail) + two queues
 namespace {
 struct Workspace { uint32_t *p = nullptr; size_t cap = 0; };
 std::mutex ws_lock;
 std::unordered_map<hipStream_t, Workspace> ws_map;
 
-hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out)
+hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out, size_t *cap_out)
 {
     std::lock_guard<std::mutex> g(ws_lock);
     Workspace &w = ws_map[stream];
@@ -667,11 +923,12 @@ hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out)
         if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
         w.p = nullptr; w.cap = 0;
         size_t cap = nblocks < 4096 ? 4096 : nblocks;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.p), (cap + 4) * sizeof(uint32_t));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.p), (2 * cap + 8) * sizeof(uint32_t));
         if (e != hipSuccess) return e;
         w.cap = cap;
     }
     *out = w.p;
+    *cap_out = w.cap;
     return hipSuccess;
 }
 } // namespace
@@ -683,20 +940,25 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (block_bytes == 0 || block_bytes > 65536 || nblocks > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
     const bool staged = n <= kStageMax;
-    const uint32_t lds = kTabBytes + (staged ? ((n + 15u) & ~15u) : 0u);
+    // staged bytes are read as aligned dwords: a size that is not a multiple of 4 gets 16 bytes of slack behind it
+    const uint32_t lds = kTabBytes + (staged ? ((n + 15u) & ~15u) + (n % 4 ? 16u : 0u) : 0u);
     static bool attr_set = false; // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_blocks_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStageMax + kTabBytes);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStageMax + kTabBytes + 16);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_parse_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kStageMax + kTabBytes + 16);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     uint32_t *ws = nullptr;
-    hipError_t e = get_workspace(stream, nblocks, &ws);
+    size_t cap = 0;
+    hipError_t e = get_workspace(stream, nblocks, &ws, &cap);
     if (e != hipSuccess) return e;
-    uint32_t *counters = ws, *queue = ws + 4;
+    uint32_t *counters = ws, *queue = ws + 8, *queue2 = ws + 8 + cap;
 
-    if ((e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), stream)) != hipSuccess) return e;
     // CW_LZ4_MODE=scan stops after the scan kernel (queued blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
     static const char *mode = getenv("CW_LZ4_MODE");
     // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
@@ -719,12 +981,26 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
     const size_t want = 256 * (per_cu > 10 ? 10 : per_cu);
     const size_t grid = nblocks < want ? nblocks : want;
+    // CW_LZ4_MODE=cut parses with the first-generation (write/read-back) kernel only (profiling knob)
+    const bool cut_only = mode && strcmp(mode, "cut") == 0;
+    if (!cut_only) {
+        if (staged)
+            hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, queue, counters, queue2);
+        else
+            hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, queue, counters, queue2);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    // blocks the exchange-based parser handed back (none, unless the LDS ever applies lanes out of order)
+    const uint32_t *q = cut_only ? queue : queue2;
+    uint32_t *c = cut_only ? counters : counters + 4;
     if (staged)
         hipLaunchKernelGGL(lz4_blocks_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                           dst_stride, sizes, queue, counters);
+                           dst_stride, sizes, q, c);
     else
         hipLaunchKernelGGL(lz4_blocks_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                           dst_stride, sizes, queue, counters);
+                           dst_stride, sizes, q, c);
     return hipGetLastError();
 }
 
