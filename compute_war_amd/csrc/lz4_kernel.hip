@@ -712,6 +712,73 @@ __device__ __forceinline__ Around around(const uint8_t *in, uint32_t p, bool has
     return a;
 }
 
+// raw head values of a search: two aligned dwords + byte shift (STAGED) or the value itself
+struct HeadRaw { uint32_t lo, hi, sh; };
+template <bool STAGED>
+__device__ __forceinline__ HeadRaw head_request(const uint8_t *in, uint32_t n, uint32_t ins, uint32_t s0, uint32_t lane)
+{
+    uint32_t p = lane == 0 ? ins : s0 - 2 + lane;
+    p = p <= n - 8 ? p : n - 8; // only positions <= n - 12 are ever used
+    HeadRaw r;
+    if (STAGED) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (p >> 2);
+        r.lo = w[0]; r.hi = w[1]; r.sh = p & 3u;
+    } else {
+        r.lo = rd32(in, p); r.hi = 0; r.sh = 0;
+    }
+    return r;
+}
+
+// result of one batch of items
+struct BatchOut { uint32_t mpos, match, mc, back; bool stop, found, broken, flong, blong; };
+
+// exchange, lane-order check, candidate test for one batch of items (lane = item)
+template <bool STAGED>
+__device__ __forceinline__ BatchOut run_batch(const uint8_t *in, uint16_t *tab, uint32_t tab_lds, uint32_t pos, uint32_t v, bool active,
+                                             bool tested, uint32_t anchor, uint32_t matchlimit, uint32_t lane)
+{
+    BatchOut r;
+    r.mpos = 0; r.match = 0; r.mc = 0; r.back = 0; r.stop = false; r.found = false; r.broken = false; r.flong = false; r.blong = false;
+    const uint32_t h = hash13(v);
+    uint32_t old = 0;
+    if (active) old = tab_exchange(tab_lds, h, pos);
+    if (__ballot(tested && old >= pos)) { r.broken = true; r.stop = true; return r; }
+    // candidate bytes, and the neighbourhood that settles short extensions in the same round
+    const bool near_start = pos < 4 || old < 4;
+    Around ap, ac;
+    ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 0; ac.after = 1;
+    if (tested) {
+        ac = around<STAGED>(in, old, !near_start);
+        ap = around<STAGED>(in, pos, !near_start); // pos <= n - 12
+    }
+    const unsigned long long eqmask = __ballot(tested && ac.at == v);
+    if (!eqmask) return r;
+    const uint32_t w = (uint32_t)__builtin_ctzll(eqmask);
+    const uint32_t pm = __builtin_amdgcn_readlane(pos | (old << 16), w);
+    r.mpos = pm & 0xFFFFu; r.match = pm >> 16;
+    // undo the speculative writes behind the match: the first lane of each slot's group got the content from before
+    // the group (a value <= mpos); later lanes of a group got a position > mpos
+    if (active && lane > w && old <= r.mpos) tab[h] = (uint16_t)old;
+    // forward: bytes 4..11; backward: up to 3 (4 = keep going)
+    const uint64_t x = ap.after ^ ac.after;
+    uint32_t nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+    const uint32_t lim = matchlimit - (pos + 4);
+    bool fl = false;
+    if (nf >= lim) nf = lim; else fl = nf == 8;
+    const uint32_t room = pos - anchor < old ? pos - anchor : old; // bytes the match may move back
+    const uint32_t y = ap.before ^ ac.before;
+    uint32_t nb = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+    bool bl = false;
+    if (near_start) { nb = 0; bl = room != 0; }
+    else if (nb >= room) nb = room;
+    else bl = nb == 4;
+    const uint32_t packed = __builtin_amdgcn_readlane(nf | (nb << 8) | ((uint32_t)fl << 16) | ((uint32_t)bl << 17), w);
+    r.mc = packed & 0xFFu; r.back = (packed >> 8) & 0xFFu;
+    r.flong = (packed >> 16) & 1u; r.blong = (packed >> 17) & 1u;
+    r.found = true; r.stop = true;
+    return r;
+}
+
 template <bool STAGED>
 __global__ void __launch_bounds__(64)
 lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
@@ -756,80 +823,42 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
         if (n >= kMFLimit + 1) {
             const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
-            // head batch of a search: lane 0 inserts `ins`, lane 1 re-tests s0-1 (= ip, after a match), lane t >= 2
-            // probes s0 + t - 2 (the first 65 probes advance by 1); the literals of the sequence start at s0-1,
-            // so literal i is the low byte of lane i+1's value
+            // Head batch of a search (almost always the only one): lane 0 inserts `ins`, lane 1 re-tests s0-1 (= ip,
+            // after a match), lane t >= 2 probes s0 + t - 2 (the first 65 probes advance by 1).  The literals of the
+            // sequence start at s0-1, so literal i is the low byte of lane i+1's value.  The values are requested as
+            // two aligned dwords per lane (STAGED) and only combined when the search starts, so that the request
+            // overlaps the emission of the previous sequence.
             uint32_t ins = 0, s0 = 1;
-            bool has_retest = false;
-            auto head_pos = [&](uint32_t ins_, uint32_t s0_) { return lane == 0 ? ins_ : s0_ - 2 + lane; };
-            uint32_t vhead;
-            {
-                const uint32_t p = head_pos(ins, s0);
-                vhead = rd32x<STAGED>(in, p <= n - 8 ? p : n - 8); // only positions <= n - 12 are ever used
-            }
+            unsigned long long lane1 = 0; // bit 1 set once there is a position to re-test
+            HeadRaw hr = head_request<STAGED>(in, n, ins, s0, lane);
 
             for (uint32_t seq = 0; seq < n; seq++) {
-                uint32_t mpos = 0, match = 0, mc = 0, back = 0;
-                bool found = false, flong = false, blong = false;
-                for (uint32_t t0 = 0;; t0 += 64) {
-                    const uint32_t t = t0 + lane, k = t - 2;
-                    const bool is_probe = t >= 2;
-                    const uint32_t dk = t0 == 0 ? k : probe_delta(k), stepk = k == 0 ? 1u : (63u + k) >> 6;
-                    const uint32_t pos = t == 0 ? ins : t == 1 ? s0 - 1 : s0 + dk;
-                    const bool dead = is_probe && s0 + dk + stepk > mflimit + 1;
-                    const bool active = !dead && (is_probe || t == 0 || has_retest);
-                    const unsigned long long amask = __ballot(active);
-                    if (!amask) break;
-
-                    uint32_t v = vhead;
-                    if (t0 != 0) v = rd32x<STAGED>(in, active ? pos : 0u);
-                    const uint32_t h = hash13(v);
-                    uint32_t old = 0;
-                    if (active) old = tab_exchange(tab_lds, h, pos);
-                    const bool tested = active && t != 0;
-                    if (__ballot(tested && old >= pos)) { broken = true; break; }
-
-                    // candidate bytes, and the neighbourhood that settles short extensions in the same round
-                    const bool near_start = pos < 4 || old < 4;
-                    Around ap, ac;
-                    ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 0; ac.after = 1;
-                    if (tested) {
-                        ac = around<STAGED>(in, old, !near_start);
-                        ap = around<STAGED>(in, pos, !near_start); // pos <= n - 12
-                    }
-                    const uint32_t c4 = ac.at, b_a = ap.before, b_b = ac.before;
-                    const uint64_t f_a = ap.after, f_b = ac.after;
-                    const bool eq = tested && c4 == v;
-                    const unsigned long long eqmask = __ballot(eq);
-                    if (eqmask) {
-                        const uint32_t w = ctz64(eqmask);
-                        const uint32_t pm = __builtin_amdgcn_readlane(pos | (old << 16), w);
-                        mpos = pm & 0xFFFFu; match = pm >> 16;
-                        // undo the speculative writes behind the match: the first lane of each slot's group got the
-                        // content from before the group (a value <= mpos); later lanes of a group got a position > mpos
-                        if (active && lane > w && old <= mpos) tab[h] = (uint16_t)old;
-                        // forward: bytes 4..11; backward: up to 3 (4 = keep going)
-                        const uint64_t x = f_a ^ f_b;
-                        uint32_t nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                        const uint32_t lim = matchlimit - (pos + 4);
-                        bool fl = false;
-                        if (nf >= lim) nf = lim; else fl = nf == 8;
-                        const uint32_t room = pos - anchor < old ? pos - anchor : old; // bytes the match may move back
-                        const uint32_t y = b_a ^ b_b;
-                        uint32_t nb = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
-                        bool bl = false;
-                        if (near_start) { nb = 0; bl = room != 0; }
-                        else if (nb >= room) nb = room;
-                        else bl = nb == 4;
-                        const uint32_t packed = __builtin_amdgcn_readlane(nf | (nb << 8) | ((uint32_t)fl << 16) | ((uint32_t)bl << 17), w);
-                        mc = packed & 0xFFu; back = (packed >> 8) & 0xFFu;
-                        flong = (packed >> 16) & 1u; blong = (packed >> 17) & 1u;
-                        found = true;
-                        break;
-                    }
-                    if (__ballot(dead)) break; // the next probe would pass the end of the block
+                const uint32_t vhead = STAGED ? __builtin_amdgcn_alignbyte(hr.hi, hr.lo, hr.sh) : hr.lo;
+                BatchOut bo;
+                {   // head batch: all steps are 1, so an item is dead iff its position is past mflimit
+                    const uint32_t pos = lane == 0 ? ins : s0 - 2 + lane;
+                    const bool live = pos <= mflimit;
+                    const unsigned long long amask = __ballot(live) & (lane1 | ~2ull);
+                    const bool active = (amask >> lane) & 1u;
+                    bo = run_batch<STAGED>(in, tab, tab_lds, pos, vhead, active, active && lane != 0, anchor, matchlimit, lane);
+                    if (!bo.stop && __ballot(!live)) bo.stop = true; // the next probe would pass the end of the block
                 }
-                if (broken || !found) break;
+                if (!bo.stop) { // rare: more than 62 probes without a match
+                    for (uint32_t t0 = 64;; t0 += 64) {
+                        const uint32_t k = t0 + lane - 2;
+                        const uint32_t dk = probe_delta(k), stepk = (63u + k) >> 6;
+                        const uint32_t p2 = s0 + dk;
+                        const bool act2 = p2 + stepk <= mflimit + 1;
+                        if (!__ballot(act2)) break;
+                        const uint32_t v2 = rd32x<STAGED>(in, act2 ? p2 : 0u);
+                        bo = run_batch<STAGED>(in, tab, tab_lds, p2, v2, act2, act2, anchor, matchlimit, lane);
+                        if (bo.stop || __ballot(!act2)) break;
+                    }
+                }
+                if (bo.broken) { broken = true; break; }
+                if (!bo.found) break;
+                uint32_t mpos = bo.mpos, match = bo.match, mc = bo.mc, back = bo.back;
+                const bool flong = bo.flong, blong = bo.blong;
 
                 if (flong) { // long match: keep counting, 64 bytes per round
                     for (;;) {
@@ -855,12 +884,8 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 if (ip < anchor || mend > n) { broken = true; break; } // cannot happen; never write out of bounds
 
                 // request the next search's head values now; the stores below do not wait for them
-                const uint32_t lit_v = vhead;
                 const bool more = mend <= mflimit;
-                if (more) {
-                    const uint32_t p = head_pos(mend - 2, mend + 1);
-                    vhead = rd32x<STAGED>(in, p <= n - 8 ? p : n - 8); // only positions <= n - 12 are ever used
-                }
+                if (more) hr = head_request<STAGED>(in, n, mend - 2, mend + 1, lane);
 
                 // ---- emit: literals [anchor, ip), offset, match length ----
                 const uint32_t lit = ip - anchor, tok_pos = op;
@@ -868,7 +893,7 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 op += 1;
                 if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
                 else token = lit << 4;
-                if (lane >= 1 && lane <= lit) out[op + lane - 1] = (uint8_t)lit_v; // literal i sits in lane i+1
+                if (lane - 1 < lit) out[op + lane - 1] = (uint8_t)vhead; // literal i sits in lane i+1 (lane 0 wraps to "no")
                 if (lit > 63) copy_out(out + op + 63, in, anchor + 63, lit - 63, lane);
                 op += lit;
                 const uint32_t off = ip - match, off_pos = op;
@@ -883,7 +908,7 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
                 anchor = mend;
                 if (!more) break; // end of parse: remaining bytes are literals
-                ins = mend - 2; s0 = mend + 1; has_retest = true;
+                ins = mend - 2; s0 = mend + 1; lane1 = 2;
             }
         }
         if (broken) {
