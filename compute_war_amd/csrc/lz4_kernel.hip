@@ -38,8 +38,15 @@
 #include <unordered_map>
 
 #include "cw_device.h"
+#include "lz_device.h"
 
 namespace cw {
+
+using lz::Around;
+using lz::around;
+using lz::rd32;
+using lz::rd32x;
+using lz::tab_exchange;
 
 namespace {
 
@@ -50,25 +57,6 @@ constexpr int kScanGroup = 16;                 // probe batches in flight per wa
 constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMFLimit = 12;
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ uint32_t rd32(const uint8_t *lds, uint32_t pos)
-{
-    uint32_t v;
-    __builtin_memcpy(&v, lds + pos, 4); // unaligned ds_read_b32
-    return v;
-}
-// 4 bytes at any offset of a block staged in LDS.  An unaligned ds_read is legal but the LDS handles it lane by lane
-// (SQ_LDS_UNALIGNED_STALL was 92 % of the LDS-busy cycles of the parse kernel, which it saturated), so: the two
-// aligned dwords around the position (one ds_read2_b32) and a byte align; callers keep pos <= n - 8, so the second
-// dword is inside the staged bytes.  Blocks read from global memory use plain unaligned loads.
-template <bool STAGED>
-__device__ __forceinline__ uint32_t rd32x(const uint8_t *in, uint32_t pos)
-{
-    if (STAGED) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (pos >> 2);
-        return __builtin_amdgcn_alignbyte(w[1], w[0], pos & 3u);
-    }
-    return rd32(in, pos);
-}
 __device__ __forceinline__ uint32_t hash13(uint32_t v) { return (v * 2654435761u) >> 19; }
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 
@@ -683,35 +671,6 @@ lz4_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
 // position and the candidate, so that matches up to 11 bytes and catch-ups up to 3 bytes (most of them) need no
 // further round.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t tab_exchange(uint32_t tab_lds, uint32_t h, uint32_t pos)
-{
-    const uint32_t addr = tab_lds + (h >> 1) * 4, sh = (h & 1) * 16;
-    uint32_t old;
-    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=v"(old) : "v"(addr), "v"(0xFFFFu << sh), "v"(pos << sh) : "memory");
-    return (old >> sh) & 0xFFFFu;
-}
-// the 16 bytes around a position: [p-4, p) (only if has_before), [p, p+4), [p+4, p+12)
-struct Around { uint32_t before, at; uint64_t after; };
-template <bool STAGED>
-__device__ __forceinline__ Around around(const uint8_t *in, uint32_t p, bool has_before)
-{
-    Around a;
-    if (STAGED) { // five aligned dwords from p-4 on; never a dword outside the staged bytes (no padding: 8 blocks of 4 KiB per CU)
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (p >> 2);
-        const uint32_t sh = p & 3u;
-        const uint32_t w0 = w[has_before ? -1 : 0], w1 = w[0], w2 = w[1], w3 = w[2], w4 = w[sh ? 3 : 2]; // p <= n - 12
-        a.before = __builtin_amdgcn_alignbyte(w1, w0, sh);
-        a.at = __builtin_amdgcn_alignbyte(w2, w1, sh);
-        a.after = __builtin_amdgcn_alignbyte(w3, w2, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32);
-    } else {
-        a.before = rd32(in, has_before ? p - 4 : 0u);
-        a.at = rd32(in, p);
-        __builtin_memcpy(&a.after, in + p + 4, 8);
-    }
-    return a;
-}
-
 // raw head values of a search: two aligned dwords + byte shift (STAGED) or the value itself
 struct HeadRaw { uint32_t lo, hi, sh; };
 template <bool STAGED>
@@ -783,7 +742,8 @@ template <bool STAGED>
 __global__ void __launch_bounds__(64)
 lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes,
-                 const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t *__restrict__ requeue)
+                 const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t *__restrict__ requeue,
+                 uint32_t force_redo)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
@@ -819,9 +779,9 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
         __syncthreads();
 
         uint32_t anchor = 0, op = 0;
-        bool broken = false; // lane-order check failed (or an impossible state): hand the block to the other parser
+        bool broken = force_redo != 0; // lane-order check failed (or an impossible state): hand the block to the other parser
 
-        if (n >= kMFLimit + 1) {
+        if (!broken && n >= kMFLimit + 1) {
             const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
             // Head batch of a search (almost always the only one): lane 0 inserts `ins`, lane 1 re-tests s0-1 (= ip,
             // after a match), lane t >= 2 probes s0 + t - 2 (the first 65 probes advance by 1).  The literals of the
@@ -1008,13 +968,16 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const size_t grid = nblocks < want ? nblocks : want;
     // CW_LZ4_MODE=cut parses with the first-generation (write/read-back) kernel only (profiling knob)
     const bool cut_only = mode && strcmp(mode, "cut") == 0;
+    // CW_LZ_FORCE_REDO=1: the exchange kernel hands every block back, as if its lane-order check had failed (test knob)
+    static const char *redo_env = getenv("CW_LZ_FORCE_REDO");
+    const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
     if (!cut_only) {
         if (staged)
             hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                               dst_stride, sizes, queue, counters, queue2);
+                               dst_stride, sizes, queue, counters, queue2, force_redo);
         else
             hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                               dst_stride, sizes, queue, counters, queue2);
+                               dst_stride, sizes, queue, counters, queue2, force_redo);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     // blocks the exchange-based parser handed back (none, unless the LDS ever applies lanes out of order)

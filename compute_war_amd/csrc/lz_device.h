@@ -1,0 +1,64 @@
+// lz_device.h -- device helpers shared by the LZ4 and LZF parse kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cw {
+namespace lz {
+
+__device__ __forceinline__ uint32_t rd32(const uint8_t *p, uint32_t pos)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p + pos, 4); // unaligned load
+    return v;
+}
+
+// 4 bytes at any offset of a block staged in LDS.  An unaligned ds_read is legal but the LDS handles it lane by lane
+// (SQ_LDS_UNALIGNED_STALL was 92 % of the LDS-busy cycles of the LZ4 parse kernel, which it saturated), so: the two
+// aligned dwords around the position (one ds_read2_b32) and a byte align; the caller guarantees that the second
+// dword is inside the staged bytes.  Blocks read from global memory use plain unaligned loads.
+template <bool STAGED>
+__device__ __forceinline__ uint32_t rd32x(const uint8_t *in, uint32_t pos)
+{
+    if (STAGED) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (pos >> 2);
+        return __builtin_amdgcn_alignbyte(w[1], w[0], pos & 3u);
+    }
+    return rd32(in, pos);
+}
+
+// Masked exchange of the 16-bit slot h of a u16 table in LDS (byte address tab_lds): stores pos, returns the previous
+// content.  ds_mskor_rtn_b32 applies the lanes of one instruction in ascending lane order (tools/mskor_order.hip),
+// so a lane also sees the stores of earlier lanes of the same instruction; callers verify that on every use.
+__device__ __forceinline__ uint32_t tab_exchange(uint32_t tab_lds, uint32_t h, uint32_t pos)
+{
+    const uint32_t addr = tab_lds + (h >> 1) * 4, sh = (h & 1) * 16;
+    uint32_t old;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(old) : "v"(addr), "v"(0xFFFFu << sh), "v"(pos << sh) : "memory");
+    return (old >> sh) & 0xFFFFu;
+}
+
+// the 16 bytes around a position: [p-4, p) (only if has_before), [p, p+4), [p+4, p+12)
+struct Around { uint32_t before, at; uint64_t after; };
+template <bool STAGED>
+__device__ __forceinline__ Around around(const uint8_t *in, uint32_t p, bool has_before)
+{
+    Around a;
+    if (STAGED) { // five aligned dwords from p-4 on; the last one only if the bytes are not dword aligned
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(in) + (p >> 2);
+        const uint32_t sh = p & 3u;
+        const uint32_t w0 = w[has_before ? -1 : 0], w1 = w[0], w2 = w[1], w3 = w[2], w4 = w[sh ? 3 : 2];
+        a.before = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        a.at = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        a.after = __builtin_amdgcn_alignbyte(w3, w2, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32);
+    } else {
+        a.before = rd32(in, has_before ? p - 4 : 0u);
+        a.at = rd32(in, p);
+        __builtin_memcpy(&a.after, in + p + 4, 8);
+    }
+    return a;
+}
+
+} // namespace lz
+} // namespace cw

@@ -20,8 +20,11 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "cw_device.h"
+#include "lz_device.h"
 
 namespace cw {
 
@@ -30,6 +33,7 @@ namespace {
 constexpr uint32_t kLzfSlots = 1u << 16, kLzfTabBytes = kLzfSlots * 2;
 constexpr uint32_t kMaxOff = 1u << 13, kMaxRef = (1u << 8) + (1u << 3), kMaxLit = 32;
 constexpr uint32_t kInLdsMax = 16384; // blocks up to this size are staged in LDS next to the table
+constexpr uint32_t kRedo = 0xFFFFFFFFu; // sizes[] marker: exchange kernel -> write/read-back kernel
 
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 __device__ __forceinline__ uint32_t lzf_slot(uint32_t b0, uint32_t b1, uint32_t b2)
@@ -55,7 +59,7 @@ __device__ __forceinline__ void put_literals(uint8_t *__restrict__ out, const ui
 
 __global__ void __launch_bounds__(64)
 lzf_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
-                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t in_lds)
+                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t in_lds, uint32_t only_marked)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
@@ -64,6 +68,9 @@ lzf_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
     const uint32_t cap = n - 1; // out_len of the reference's call
 
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        // second pass behind lzf_parse_kernel: only the blocks it handed back (none, unless the LDS ever applies the
+        // lanes of an exchange out of order)
+        if (only_marked && __builtin_amdgcn_readfirstlane(sizes[blk]) != kRedo) continue;
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
 
@@ -177,6 +184,196 @@ lzf_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Second generation (same idea as lz4_parse_kernel): the table operation of a batch is one ds_mskor_rtn_b32 -- a
+// masked 16-bit exchange whose lanes the LDS applies in ascending order -- so every lane gets back exactly the
+// reference the serial parser would have read at its position, including the stores of earlier lanes of the batch:
+// no write/read-back round and no cutting of batches.  The order is verified on every batch (a returned reference
+// >= the lane's own position cannot occur serially); a block where it fails is marked and redone by
+// lzf_blocks_kernel.  Lanes 0 and 1 of a batch re-insert the last two positions of the previous match (VERY_FAST),
+// lane j >= 2 takes position ip + j - 2.  Per batch: one round for the 4 bytes at every position (requested before
+// the previous sequence is emitted; their low bytes are the literals, stored from registers), one exchange, one
+// round for the 16 bytes at position and reference (match test + the first 9 bytes of the extension).
+// Staged blocks are read as aligned dwords + v_alignbyte (unaligned ds_reads serialise the LDS).
+// ---------------------------------------------------------------------------------------------------
+template <bool STAGED>
+__global__ void __launch_bounds__(64)
+lzf_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
+                 uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t force_redo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+    uint8_t *stage = smem + kLzfTabBytes;
+    const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(tab);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cap = n - 1; // out_len of the reference's call
+
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        if (force_redo) { // test knob: behave as if the lane-order check had failed
+            if (lane == 0) sizes[blk] = kRedo;
+            continue;
+        }
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+
+        __syncthreads();
+        for (uint32_t i = lane; i < kLzfTabBytes / 16; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0, 0, 0, 0);
+        const uint8_t *in = STAGED ? stage : g;
+        if (STAGED) {
+            for (uint32_t i = lane; i < n; i += 64) stage[i] = g[i];
+            if (lane < 16) stage[n + lane] = 0; // slack read by the dword loads (never compared as data)
+        }
+        __syncthreads();
+
+        uint32_t ip = 0, op = 1, lit = 0; // op = 1: the first literal run's control byte is reserved
+        bool fail = (n == 0 || cap == 0), broken = false, has_q = false;
+
+        // the 4 bytes at every position of a batch; a global read must not pass the end of the block
+        auto request = [&](uint32_t ip_) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t pos = ip_ - 2 + lane;
+            if (STAGED) return lz::rd32x<true>(in, (int32_t)pos < 0 ? 0u : pos + 2 < n ? pos : 0u);
+            const uint32_t p = (int32_t)pos < 0 || pos + 2 >= n ? 0u : pos;
+            const uint32_t q = p + 4 <= n ? p : p - 1; // pos = n - 3: read one byte earlier and shift
+            return n >= 4 ? lz::rd32(in, q) >> ((p - q) * 8) : 0u;
+        };
+        uint32_t vnext = (!fail && n >= 4) ? request(0) : 0u;
+        if (n < 4) { // too small for the dword reads (cannot compress anyway): byte-wise values
+            const uint32_t pos = lane - 2;
+            vnext = 0;
+            if ((int32_t)pos >= 0 && pos + 2 < n) vnext = in[pos] | (in[pos + 1] << 8) | (in[pos + 2] << 16);
+        }
+
+        while (!fail && ip + 2 < n) {
+            // ---- one batch: lanes 0,1 re-insert ip-2, ip-1 (after a match), lane j >= 2 takes position ip + j - 2 ----
+            const uint32_t pos = ip - 2 + lane;
+            const bool tested = lane >= 2 && pos + 2 < n;
+            const bool active = tested || (lane < 2 && has_q);
+            const uint32_t ntest = (uint32_t)__builtin_popcountll(__ballot(tested));
+            const uint32_t v = vnext;
+            const uint32_t b0 = v & 0xFFu, b1 = (v >> 8) & 0xFFu, b2 = (v >> 16) & 0xFFu;
+            const uint32_t slot = lzf_slot(b0, b1, b2);
+            uint32_t old = 0;
+            if (active) old = lz::tab_exchange(tab_lds, slot, pos);
+            if (__ballot(tested && old >= pos && (old | pos) != 0)) { broken = true; break; } // (position 0 finds the empty slot: 0)
+
+            // the parser's match test ("ref > in_data" excludes the empty slot) + the neighbourhood for the extension
+            const bool cand = tested && old > 0 && pos - old - 1 < kMaxOff;
+            const bool wide = STAGED || pos + 12 <= n; // all 16 bytes readable (reference < position)
+            lz::Around ap, ac;
+            ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 1u << 24; ac.after = 1;
+            if (cand) {
+                if (wide) {
+                    ac = lz::around<STAGED>(in, old, false);
+                    ap = lz::around<STAGED>(in, pos, false);
+                } else {
+                    ac.at = in[old] | (in[old + 1] << 8) | (in[old + 2] << 16) | (~v & 0xFF000000u); // 4th byte: "differs"
+                }
+            }
+            const unsigned long long mm = __ballot(cand && ((ac.at ^ v) & 0xFFFFFFu) == 0);
+            const uint32_t w = mm ? (uint32_t)__builtin_ctzll(mm) : 64u;
+
+            // ---- the positions before the match (or the whole batch) are literals ----
+            const uint32_t nlit = mm ? w - 2 : ntest;
+            uint32_t ref = 0, mpos = 0, eqs = 0;
+            bool more_eq = false;
+            if (mm) {
+                const uint32_t pm = __builtin_amdgcn_readlane(pos | (old << 16), w);
+                mpos = pm & 0xFFFFu; ref = pm >> 16;
+                // undo the speculative stores behind the match (first lane of each slot's group restores the slot)
+                if (active && lane > w && old <= mpos) tab[slot] = (uint16_t)old;
+                // equal bytes from index 3 on: byte 3 is the top byte of `at`, bytes 4..11 are `after`
+                const uint64_t x = ap.after ^ ac.after;
+                uint32_t e = (ac.at ^ v) >> 24 ? 0u : 1u + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u);
+                bool me = wide ? e == 9 : true; // not wide: nothing was compared beyond the 3 bytes
+                if (!wide) e = 0;
+                const uint32_t packed = __builtin_amdgcn_readlane(e | ((uint32_t)me << 8), w);
+                eqs = packed & 0xFFu; more_eq = (packed >> 8) & 1u;
+            }
+            if (nlit) {
+                // each literal checks op < out_end before it is stored; positions grow, so test the last one
+                const uint32_t last = op + (nlit - 1) + (lit + nlit - 1) / kMaxLit;
+                if (last >= cap) { fail = true; break; }
+                const uint32_t i = lane - 2; // literal i = low byte of lane i + 2
+                if (i < nlit) {
+                    const uint32_t t = lit + i, p = op + i + t / kMaxLit;
+                    out[p] = (uint8_t)b0;
+                    if ((t + 1) % kMaxLit == 0) out[p - kMaxLit] = kMaxLit - 1; // this byte completed a run of 32
+                }
+                op += nlit + (lit + nlit) / kMaxLit; // every completed run also reserved the next control byte
+                lit = (lit + nlit) % kMaxLit;
+                ip += nlit;
+            }
+            if (!mm) { // no match among the tested positions: next batch starts behind them, nothing to re-insert
+                has_q = false;
+                if (ip + 2 < n) vnext = request(ip);
+                continue;
+            }
+
+            // ---- match at ip (= mpos) against ref ----
+            uint32_t maxlen = n - ip - 2;
+            if (maxlen > kMaxRef) maxlen = kMaxRef;
+            if (op + 4 >= cap && op - (lit == 0) + 4 >= cap) { fail = true; break; }
+            if (lit) { if (lane == 0) out[op - lit - 1] = (uint8_t)(lit - 1); } // stop run
+            else op -= 1;                                                        // undo an empty run
+
+            // eq = number of equal bytes from index 3 on (bounded by the block end and the longest reference)
+            uint32_t eq = eqs;
+            {
+                const uint32_t room = (n - ip < kMaxRef + 2 ? n - ip : kMaxRef + 2) - 3; // indices 3 .. room+2 may be compared
+                if (eq >= room) { eq = room; more_eq = false; }
+            }
+            while (more_eq) {
+                const uint32_t t = 3 + eq + lane;
+                const bool ok = ip + t < n && t < kMaxRef + 2 && in[ref + t] == in[ip + t];
+                const uint32_t cnt = ctz64(~__ballot(ok));
+                eq += cnt;
+                if (cnt < 64) break;
+            }
+            uint32_t len; // matched octets, with the reference's unrolled-compare overshoot
+            if (maxlen > 16) {
+                if (eq < 16) len = 3 + eq;
+                else { len = 3 + eq < maxlen ? 3 + eq : maxlen; if (len < 19) len = 19; }
+            } else {
+                len = 3 + eq < maxlen ? 3 + eq : maxlen;
+                if (len < 3) len = 3;
+            }
+            const uint32_t off = ip - ref - 1, l2 = len - 2, at = op;
+            op += l2 < 7 ? 2 : 3;
+            lit = 0; op += 1; // start run
+            ip += len;
+            has_q = true;
+            const bool go_on = ip + 2 < n;
+            if (go_on) vnext = request(ip); // before the stores: they do not wait for it
+            if (lane == 0) {
+                if (l2 < 7) {
+                    out[at] = (uint8_t)((off >> 8) + (l2 << 5));
+                    out[at + 1] = (uint8_t)off;
+                } else {
+                    out[at] = (uint8_t)((off >> 8) + (7u << 5));
+                    out[at + 1] = (uint8_t)(l2 - 7);
+                    out[at + 2] = (uint8_t)off;
+                }
+            }
+            if (!go_on) break;
+        }
+
+        if (broken) {
+            if (lane == 0) sizes[blk] = kRedo;
+            continue;
+        }
+        if (!fail) {
+            if (op + 3 > cap) { // at most 3 bytes can be missing here
+                fail = true;
+            } else {
+                if (ip < n) put_literals(out, in, ip, n - ip, op, lit, lane);
+                if (lit) { if (lane == 0) out[op - lit - 1] = (uint8_t)(lit - 1); } // end run
+                else op -= 1;
+            }
+        }
+        if (lane == 0) sizes[blk] = fail ? 0u : op;
+    }
+}
+
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {
@@ -184,17 +381,35 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (block_bytes == 0 || block_bytes > 65536) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
     const uint32_t in_lds = n <= kInLdsMax ? 1u : 0u;
-    const uint32_t lds = kLzfTabBytes + (in_lds ? ((n + 15u) & ~15u) : 0u);
+    const uint32_t lds = kLzfTabBytes + (in_lds ? ((n + 15u) & ~15u) + 16u : 0u); // 16 bytes of slack for dword reads
     static bool attr_set = false; // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_blocks_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kInLdsMax);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kInLdsMax + 16);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_parse_kernel<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kInLdsMax + 16);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_parse_kernel<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const size_t grid = nblocks < 256 ? nblocks : 256; // the 128 KiB table admits one workgroup per CU
+    static const char *mode = getenv("CW_LZF_MODE"); // CW_LZF_MODE=cut: write/read-back kernel only (profiling knob)
+    const bool cut_only = mode && strcmp(mode, "cut") == 0;
+    static const char *redo_env = getenv("CW_LZ_FORCE_REDO"); // test knob, see lz4_kernel.hip
+    const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
+    if (!cut_only) {
+        if (in_lds)
+            hipLaunchKernelGGL(lzf_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, force_redo);
+        else
+            hipLaunchKernelGGL(lzf_parse_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, force_redo);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes, in_lds);
+                       dst_stride, sizes, in_lds, cut_only ? 0u : 1u);
     return hipGetLastError();
 }
 

@@ -434,3 +434,31 @@ def test_full_size_properties(cw, oracle):
     cw.dev_hash("skein512", src.data_ptr() + (nb // 2) * bs, bs, nb // 2, dig2.data_ptr(), s)
     torch.cuda.synchronize()
     assert torch.equal(dig2, dig[nb // 2:])
+
+
+def test_lane_order_fallback_path_is_exact():
+    """The exchange-based LZ4/LZF parsers hand a block to the write/read-back parsers when their lane-order check
+    fails.  That never happens on this hardware, so the hand-over is forced (CW_LZ_FORCE_REDO=1, read once per
+    process -> subprocess) and the result compared with the normal path's, which the tests above pin to the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, compute_war_amd as cw\n"
+        "from conftest import corpus_file\n"
+        "cw.init(0)\n"
+        "data = corpus_file('lcet10.txt')[:6*65536] + bytes(65536) + corpus_file('kennedy.xls')[:5*65536]\n"
+        "for alg in ('lz4', 'lzf'):\n"
+        "    for bs in (4096, 65536):\n"
+        "        sizes, payload = cw.compress_blocks(alg, data, bs)\n"
+        "        h = hashlib.sha256(sizes.tobytes())\n"
+        "        for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
+        "        print(alg, bs, int(sizes.sum()), h.hexdigest())\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({}, {"CW_LZ_FORCE_REDO": "1"}):
+        import os
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 4
