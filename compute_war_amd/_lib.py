@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "cw_decompress_lz4", "cw_decompress_lzf",
     "cw_hash_blocks", "cw_compress_blocks", "cw_hash_and_compress_blocks", "cw_decompress_blocks",
     "cw_dev_hash", "cw_dev_compress", "cw_dev_hash_and_compress", "cw_dev_gen_random", "cw_dev_sum_sizes",
-    "cw_dev_decompress", "cw_profile_enable", "cw_profile_read",
+    "cw_dev_decompress", "cw_dev_pack", "cw_profile_enable", "cw_profile_read",
     "cw_offload_create", "cw_offload_destroy", "cw_offload_reset", "cw_offload_enqueue", "cw_offload_start",
     "cw_offload_complete", "cw_offload_completed", "cw_offload_state", "cw_offload_do",
     "cw_offload_thread_start", "cw_offload_submit", "cw_offload_thread_stop",
@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         "cw_dev_gen_random": ([C.c_uint64, C.c_uint64, sz, sz, vp, vp], C.c_int),
         "cw_dev_sum_sizes": ([u32p, sz, C.c_uint32, vp, vp], C.c_int),
         "cw_dev_decompress": ([C.c_int, vp, sz, u32p, sz, vp, sz, u32p, vp], C.c_int),
+        "cw_dev_pack": ([vp, sz, u32p, sz, vp, vp, vp], C.c_int),
         "cw_profile_enable": ([C.c_int], None), "cw_profile_read": ([vp, vp, C.c_int], C.c_int),
         "cw_offload_create": ([C.c_int, C.c_int, sz], vp), "cw_offload_destroy": ([vp], None),
         "cw_offload_reset": ([vp, vp, vp, ON_COMPLETE, vp], C.c_int),

@@ -93,6 +93,22 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+struct PinnedBuf { // host staging for the packed stream (one large D2H instead of one per block)
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return CW_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n < (1u << 20) ? (1u << 20) : n;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(CW_ERR_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+        cap = want;
+        return CW_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
 
 // fork/join helper for cw_dev_hash_and_compress: the codec runs on a side stream beside the hash
 struct SideStream {
@@ -122,7 +138,8 @@ thread_local SideStream t_side;
 
 struct ThreadCtx {
     hipStream_t stream = nullptr;
-    DevBuf src, dst, dig, sizes;
+    DevBuf src, dst, dig, sizes, pack, offs;
+    PinnedBuf hpack;
     bool ready = false;
     int open()
     {
@@ -137,7 +154,7 @@ struct ThreadCtx {
     ~ThreadCtx()
     {
         if (!ready) return;
-        src.release(); dst.release(); dig.release(); sizes.release();
+        src.release(); dst.release(); dig.release(); sizes.release(); pack.release(); offs.release(); hpack.release();
         (void)hipStreamDestroy(stream);
     }
 };
@@ -324,6 +341,18 @@ int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, cons
     return CW_OK;
 }
 
+int cw_dev_pack(const void *d_slots, size_t slot_stride, const uint32_t *d_sizes, size_t nblocks, void *d_packed, uint64_t *d_offsets,
+                void *stream)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    if (!d_offsets || (nblocks && (!d_sizes || (d_packed && !d_slots)))) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
+    hipError_t e = cw::pack_launch((const uint8_t *)d_slots, slot_stride, d_sizes, nblocks, (uint8_t *)d_packed, d_offsets,
+                                   (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CW_ERR_HIP, "pack launch: %s", hipGetErrorString(e));
+    return CW_OK;
+}
+
 int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, void *d_dst, void *stream)
 {
     int rc = ensure_init();
@@ -383,14 +412,16 @@ int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, siz
     // The caller's slot may be the reference's (2*l for lz4, l-1 for lzf, :234-239); device slots use the bound.
     const size_t d_stride = (bound + 15) & ~(size_t)15;
 
-    const size_t per_block = block_bytes + (do_comp ? d_stride : 0) + 64;
+    const size_t per_block = block_bytes + (do_comp ? 2 * d_stride + 8 : 0) + 64; // input, slots, packed stream, digest/size/offset
     size_t chunk = kMaxChunkBytes / (per_block ? per_block : 1);
     if (chunk == 0) chunk = 1;
     if (chunk > nblocks) chunk = nblocks;
 
     if ((rc = c.src.reserve(chunk * block_bytes + 16)) != CW_OK) return rc;
     if (do_hash && (rc = c.dig.reserve(chunk * db)) != CW_OK) return rc;
-    if (do_comp && ((rc = c.dst.reserve(chunk * d_stride)) != CW_OK || (rc = c.sizes.reserve(chunk * 4)) != CW_OK)) return rc;
+    if (do_comp && ((rc = c.dst.reserve(chunk * d_stride)) != CW_OK || (rc = c.sizes.reserve(chunk * 4)) != CW_OK ||
+                    (rc = c.pack.reserve(chunk * d_stride)) != CW_OK || (rc = c.offs.reserve((chunk + 1) * 8)) != CW_OK))
+        return rc;
 
     for (size_t first = 0; first < nblocks; first += chunk) {
         const size_t n = nblocks - first < chunk ? nblocks - first : chunk;
@@ -407,14 +438,30 @@ int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, siz
             HIP_TRY(hipMemcpyAsync((uint8_t *)digests + first * db, c.dig.p, n * db, hipMemcpyDeviceToHost, c.stream));
         }
         if (do_comp) {
+            // the slots are packed into one stream on the device (pack_kernels.hip) so that the payload of the whole
+            // batch crosses the bus in one copy; the caller's slots (which may be smaller than the bound) are filled
+            // from the pinned staging buffer
+            hipError_t pe = cw::pack_launch((const uint8_t *)c.dst.p, d_stride, (const uint32_t *)c.sizes.p, n, (uint8_t *)c.pack.p,
+                                            (uint64_t *)c.offs.p, c.stream);
+            if (pe != hipSuccess) return fail(CW_ERR_HIP, "pack launch: %s", hipGetErrorString(pe));
             HIP_TRY(hipMemcpyAsync(sizes + first, c.sizes.p, n * 4, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipStreamSynchronize(c.stream));
-            // copy back only the bytes each block produced (the caller's slot may be smaller than the bound)
+            size_t total = 0;
             for (size_t i = 0; i < n; i++) {
                 const uint32_t sz = sizes[first + i];
                 if (sz > dst_stride) return fail(CW_ERR_BAD_ARG, "block %zu: %u bytes exceed dst_stride %zu", first + i, sz, dst_stride);
-                if (sz) HIP_TRY(hipMemcpyAsync((uint8_t *)dst + (first + i) * dst_stride, (uint8_t *)c.dst.p + i * d_stride, sz,
-                                               hipMemcpyDeviceToHost, c.stream));
+                total += sz;
+            }
+            if (total) {
+                if ((rc = c.hpack.reserve(total)) != CW_OK) return rc;
+                HIP_TRY(hipMemcpyAsync(c.hpack.p, c.pack.p, total, hipMemcpyDeviceToHost, c.stream));
+                HIP_TRY(hipStreamSynchronize(c.stream));
+                const uint8_t *from = (const uint8_t *)c.hpack.p;
+                for (size_t i = 0; i < n; i++) {
+                    const uint32_t sz = sizes[first + i];
+                    memcpy((uint8_t *)dst + (first + i) * dst_stride, from, sz);
+                    from += sz;
+                }
             }
         }
         HIP_TRY(hipStreamSynchronize(c.stream));

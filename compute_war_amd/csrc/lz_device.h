@@ -60,5 +60,33 @@ __device__ __forceinline__ Around around(const uint8_t *in, uint32_t p, bool has
     return a;
 }
 
+// wavefront copy global -> global, any alignment: aligned 16 B stores fed by unaligned 16 B loads
+__device__ __forceinline__ void copy_g2g(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t len, uint32_t lane)
+{
+    if (len < 64) {
+        if (lane < len) d[lane] = s[lane];
+        return;
+    }
+    const uint32_t head = (uint32_t)(0 - reinterpret_cast<uintptr_t>(d)) & 15u;
+    if (lane < head) d[lane] = s[lane];
+    d += head; s += head; len -= head;
+    const uint32_t nvec = len >> 4;
+    uint32_t i = lane;
+    for (; i + 15 * 64 < nvec; i += 16 * 64) { // 16 KiB in flight per wavefront
+        uint4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) __builtin_memcpy(&v[u], s + 16 * (size_t)(i + 64 * u), 16);
+#pragma unroll
+        for (int u = 0; u < 16; u++) *reinterpret_cast<uint4 *>(d + 16 * (size_t)(i + 64 * u)) = v[u];
+    }
+    for (; i < nvec; i += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, s + 16 * (size_t)i, 16);
+        *reinterpret_cast<uint4 *>(d + 16 * (size_t)i) = v;
+    }
+    const uint32_t done = nvec << 4, tail = len - done;
+    if (lane < tail) d[done + lane] = s[done + lane];
+}
+
 } // namespace lz
 } // namespace cw

@@ -162,6 +162,11 @@ def dev_decompress(alg, d_comp: int, comp_stride: int, d_sizes: int, nblocks: in
     check(lib().cw_dev_decompress(_comp_id(alg), d_comp, comp_stride, d_sizes, nblocks, d_dst, block_bytes, d_status, stream))
 
 
+def dev_pack(d_slots: int, slot_stride: int, d_sizes: int, nblocks: int, d_packed: int, d_offsets: int, stream: int = 0) -> None:
+    """Packed stream + u64 block index (nblocks + 1 offsets) from fixed-stride slots; d_packed = 0: index only."""
+    check(lib().cw_dev_pack(d_slots, slot_stride, d_sizes, nblocks, d_packed or None, d_offsets, stream))
+
+
 def dev_gen_random(seed: int, first_block: int, nblocks: int, block_bytes: int, d_dst: int, stream: int = 0) -> None:
     check(lib().cw_dev_gen_random(seed, first_block, nblocks, block_bytes, d_dst, stream))
 

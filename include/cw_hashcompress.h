@@ -124,6 +124,12 @@ int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size
  * block_bytes.  Used as the reference-independent round-trip verifier of the compressors.                     */
 int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, const uint32_t *d_sizes, size_t nblocks,
                       void *d_dst, size_t block_bytes, uint32_t *d_status, void *stream);
+/* Packed output stream + block index: d_offsets[i] = sum of d_sizes[0..i) (u64, nblocks + 1
+ * entries, the last one is the total); slot i's d_sizes[i] bytes are copied to d_packed + d_offsets[i].  A block that
+ * did not fit (size 0) occupies nothing.  d_packed may be NULL: index only.  d_packed needs sum(d_sizes) bytes
+ * (at most nblocks * slot_stride).                                                                              */
+int cw_dev_pack(const void *d_slots, size_t slot_stride, const uint32_t *d_sizes, size_t nblocks,
+                void *d_packed, uint64_t *d_offsets, void *stream);
 /* synthetic input: u64 word w of block b = splitmix64(seed ^ (b << 13 | w)) */
 int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes,
                       void *d_dst, void *stream);

@@ -99,3 +99,30 @@ def test_host_decompress_blocks_and_slots(alg):
     assert cw.do_decompression(alg, comp, 2 * bs) == blk
     assert cw.do_decompression(alg, comp[:-3], 2 * bs) == b""          # truncated slot = malformed
     assert cw.do_decompression(alg, comp, bs - 1) == b""               # capacity below the block size
+
+
+@pytest.mark.parametrize("nb", [1, 63, 4096, 4097, 70001])
+def test_dev_pack_stream_and_index(cw, nb):
+    """N4: packed stream + u64 block index from fixed-stride slots (ragged sizes, zeros, several scan tiles)."""
+    import torch
+    rng = np.random.default_rng(nb)
+    stride = 272
+    sizes = rng.integers(0, stride + 1, nb, dtype=np.uint32)
+    sizes[rng.integers(0, nb, max(1, nb // 7))] = 0          # "did not fit" blocks occupy nothing
+    slots = rng.integers(0, 256, (nb, stride), dtype=np.uint8)
+    d_slots, d_sizes = torch.from_numpy(slots).cuda(), torch.from_numpy(sizes.view(np.int32)).cuda()
+    d_off = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+    d_out = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    cw.dev_pack(d_slots.data_ptr(), stride, d_sizes.data_ptr(), nb, d_out.data_ptr(), d_off.data_ptr(), s)
+    torch.cuda.synchronize()
+    want_off = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    assert np.array_equal(d_off.cpu().numpy(), want_off)
+    want = np.concatenate([slots[i, :sizes[i]] for i in range(nb)]) if sizes.sum() else np.zeros(0, np.uint8)
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:len(want)], want) and not got[len(want):].any()
+    # index only
+    d_off.zero_()
+    cw.dev_pack(0, stride, d_sizes.data_ptr(), nb, 0, d_off.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_off.cpu().numpy(), want_off)
