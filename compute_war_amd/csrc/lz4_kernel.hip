@@ -40,6 +40,10 @@
 #include "cw_device.h"
 #include "lz_device.h"
 
+#ifndef HEADW_GLOBAL
+#define HEADW_GLOBAL 16
+#endif
+
 namespace cw {
 
 using lz::Around;
@@ -718,6 +722,11 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                  const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t *__restrict__ requeue,
                  uint32_t force_redo)
 {
+    // Width of the head batch.  A wavefront waits for the slowest lane of a round, and when the block is read from
+    // global memory the candidates of far lanes are arbitrary earlier positions (L2 misses): items beyond the first
+    // few are rarely needed (text: 0.9 literals per sequence at 64 KiB), so only kHead of them are speculated on.
+    constexpr uint32_t kHead = STAGED ? 64 : HEADW_GLOBAL;
+    constexpr unsigned long long kHeadMask = kHead >= 64 ? ~0ull : (1ull << (kHead & 63)) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
     uint8_t *lds_in = smem + kTabBytes;
@@ -771,13 +780,13 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 {   // head batch: all steps are 1, so an item is dead iff its position is past mflimit
                     const uint32_t pos = lane == 0 ? ins : s0 - 2 + lane;
                     const bool live = pos <= mflimit;
-                    const unsigned long long amask = __ballot(live) & (lane1 | ~2ull);
+                    const unsigned long long amask = __ballot(live) & (lane1 | ~2ull) & kHeadMask;
                     const bool active = (amask >> lane) & 1u;
                     bo = run_batch<STAGED>(in, tab, tab_lds, pos, vhead, active, active && lane != 0, anchor, matchlimit, lane);
-                    if (!bo.stop && __ballot(!live)) bo.stop = true; // the next probe would pass the end of the block
+                    if (!bo.stop && (__ballot(!live) & kHeadMask)) bo.stop = true; // the next probe would pass the end of the block
                 }
-                if (!bo.stop) { // rare: more than 62 probes without a match
-                    for (uint32_t t0 = 64;; t0 += 64) {
+                if (!bo.stop) { // rare: more than kHead - 2 probes without a match
+                    for (uint32_t t0 = kHead;; t0 += 64) {
                         const uint32_t k = t0 + lane - 2;
                         const uint32_t dk = probe_delta(k), stepk = (63u + k) >> 6;
                         const uint32_t p2 = s0 + dk;
