@@ -43,6 +43,9 @@
 #ifndef HEADW_GLOBAL
 #define HEADW_GLOBAL 16
 #endif
+#ifndef HEADW_STAGED
+#define HEADW_STAGED 64
+#endif
 
 namespace cw {
 
@@ -725,7 +728,7 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     // Width of the head batch.  A wavefront waits for the slowest lane of a round, and when the block is read from
     // global memory the candidates of far lanes are arbitrary earlier positions (L2 misses): items beyond the first
     // few are rarely needed (text: 0.9 literals per sequence at 64 KiB), so only kHead of them are speculated on.
-    constexpr uint32_t kHead = STAGED ? 64 : HEADW_GLOBAL;
+    constexpr uint32_t kHead = STAGED ? HEADW_STAGED : HEADW_GLOBAL;
     constexpr unsigned long long kHeadMask = kHead >= 64 ? ~0ull : (1ull << (kHead & 63)) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);

@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "cw_device.h"
 #include "lz_device.h"
 
@@ -374,6 +377,246 @@ lzf_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small blocks (<= 16 KiB; the reference's own block size is 4 KiB): parse WITHOUT the 128 KiB table, so that a CU
+// holds a dozen blocks instead of one.  The table answers "latest INSERTED earlier position with my slot".  Which
+// positions are inserted depends on the parse (the inside of a match is skipped, its last two positions are not),
+// but "latest EARLIER position with my slot, inserted or not" does not: that is a per-position link that can be
+// computed for the whole block up front.  The parser's reference is then the first INSERTED position on the chain
+// link[p], link[link[p]], ..., and "skipped" is one flag per position set when a match is emitted.
+//   lzf_links_kernel  (one wavefront and one 128 KiB table per CU, but throughput- not latency-bound: 256 positions
+//                      per exchange round, loads one round ahead)  writes link[] (u16 per position) to a workspace;
+//   lzf_chain_kernel  holds link[] + flags (2n bytes) and the block (n bytes) in LDS: 12.3 KiB per 4 KiB block.  There is no
+//                      table write during the parse, hence no rollback and no ordering assumption in this kernel;
+//                      lanes walk their chains in lockstep (one aligned u16 read per step), only kChainHead
+//                      positions per batch are speculated on so that the slowest chain of a batch stays short.
+// The lane-order check sits in lzf_links_kernel (a link >= its own position); a failing block is marked and parsed
+// by lzf_blocks_kernel like everywhere else.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kChainMax = 16384, kChainHead = 16, kSkipFlag = 0x8000u;
+
+// 3 bytes at pos (as the low 24 bits) from global memory without reading past the block
+__device__ __forceinline__ uint32_t load3(const uint8_t *g, uint32_t n, uint32_t pos, bool ok)
+{
+    const uint32_t p = ok ? pos : 0u;
+    const uint32_t q = p + 4 <= n ? p : p - 1; // pos = n - 3: read one byte earlier and shift
+    return lz::rd32(g, q) >> ((p - q) * 8);
+}
+
+__global__ void __launch_bounds__(64)
+lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint16_t *__restrict__ links,
+                 uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    const uint32_t lane = threadIdx.x;
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const uint8_t *g = src + blk * src_stride;
+        uint16_t *out = links + blk * (size_t)n2;
+        __syncthreads();
+        for (uint32_t i = lane; i < kLzfTabBytes / 16; i += 64) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        bool bad = force_redo != 0;
+        uint32_t vn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t pos = 64 * k + lane; vn[k] = load3(g, n, pos, pos + 2 < n); }
+        for (uint32_t base = 0; base + 2 < n && !bad; base += 256) {
+            uint32_t addr[4], mask[4], data[4], old[4], sh[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t pos = base + 64 * k + lane, v = vn[k];
+                ok[k] = pos + 2 < n;
+                const uint32_t slot = lzf_slot(v & 0xFFu, (v >> 8) & 0xFFu, (v >> 16) & 0xFFu);
+                sh[k] = (slot & 1u) * 16;
+                addr[k] = tab_lds + (slot >> 1) * 4;
+                mask[k] = ok[k] ? 0xFFFFu << sh[k] : 0u; // a lane without a position exchanges nothing
+                data[k] = ok[k] ? pos << sh[k] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t pos = base + 256 + 64 * k + lane; vn[k] = load3(g, n, pos, pos + 2 < n); }
+            // four exchanges back to back: the LDS runs them in order, lanes ascending inside each
+            asm volatile("ds_mskor_rtn_b32 %0, %4, %8, %12\n\t"
+                         "ds_mskor_rtn_b32 %1, %5, %9, %13\n\t"
+                         "ds_mskor_rtn_b32 %2, %6, %10, %14\n\t"
+                         "ds_mskor_rtn_b32 %3, %7, %11, %15\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                         : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]),
+                           "v"(data[0]), "v"(data[1]), "v"(data[2]), "v"(data[3])
+                         : "memory");
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t pos = base + 64 * k + lane;
+                const uint32_t o = ok[k] ? (old[k] >> sh[k]) & 0xFFFFu : 0u;
+                if (__ballot(ok[k] && o >= pos && (o | pos) != 0)) bad = true; // not in lane order
+                if (pos < n2) out[pos] = (uint16_t)o;
+            }
+        }
+        if (bad && lane == 0) sizes[blk] = kRedo;
+        else if (lane == 0) sizes[blk] = 0; // "links are valid" for lzf_chain_kernel
+    }
+}
+
+__global__ void __launch_bounds__(64)
+lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst,
+                 size_t dst_stride, uint32_t *__restrict__ sizes, const uint16_t *__restrict__ links, uint32_t n2,
+                 uint32_t *__restrict__ counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *E = reinterpret_cast<uint16_t *>(smem);          // link | kSkipFlag, n2 entries
+    uint8_t *stage = smem + 2 * (size_t)n2;                     // the block, + 16 bytes of slack
+    __shared__ uint32_t mailbox;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cap = n - 1;
+
+    for (;;) {
+        // blocks are handed out dynamically: their parse times differ by an order of magnitude
+        __syncthreads();
+        if (lane == 0) mailbox = atomicAdd(counter, 1u);
+        __syncthreads();
+        const size_t blk = mailbox;
+        if (blk >= nblocks) break;
+        if (__builtin_amdgcn_readfirstlane(sizes[blk]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+        {
+            const uint4 *l4 = reinterpret_cast<const uint4 *>(links + blk * (size_t)n2);
+            for (uint32_t i = lane; i < n2 / 8; i += 64) reinterpret_cast<uint4 *>(E)[i] = l4[i];
+            for (uint32_t i = lane; i < n; i += 64) stage[i] = g[i];
+            if (lane < 16) stage[n + lane] = 0;
+        }
+        __syncthreads();
+        const uint8_t *in = stage;
+
+        uint32_t ip = 0, op = 1, lit = 0;
+        bool fail = (n == 0 || cap == 0);
+        auto request = [&](uint32_t ip_) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t pos = ip_ + lane;
+            return lz::rd32x<true>(in, pos + 2 < n ? pos : 0u);
+        };
+        uint32_t vnext = fail ? 0u : request(0);
+
+        while (!fail && ip + 2 < n) {
+            const uint32_t pos = ip + lane;
+            const bool tested = lane < kChainHead && pos + 2 < n;
+            const uint32_t ntest = (uint32_t)__builtin_popcountll(__ballot(tested));
+            const uint32_t v = vnext;
+            // the reference the serial parser would read: first position on the link chain that was inserted
+            uint32_t cur = tested ? E[pos] & 0x7FFFu : 0u;
+            for (;;) {
+                const uint32_t e = cur ? E[cur] : 0u;
+                const bool skipped = (e & kSkipFlag) != 0;
+                if (skipped) cur = e & 0x7FFFu;
+                if (!__ballot(skipped)) break;
+            }
+            const uint32_t old = cur;
+            const bool cand = tested && old > 0 && pos - old - 1 < kMaxOff;
+            lz::Around ap, ac;
+            ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 1u << 24; ac.after = 1;
+            if (cand) {
+                ac = lz::around<true>(in, old, false);
+                ap = lz::around<true>(in, pos, false);
+            }
+            const unsigned long long mm = __ballot(cand && ((ac.at ^ v) & 0xFFFFFFu) == 0);
+            const uint32_t w = mm ? (uint32_t)__builtin_ctzll(mm) : 64u;
+
+            const uint32_t nlit = mm ? w : ntest;
+            uint32_t ref = 0, eqs = 0;
+            bool more_eq = false;
+            if (mm) {
+                const uint64_t x = ap.after ^ ac.after;
+                const uint32_t e = (ac.at ^ v) >> 24 ? 0u : 1u + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u);
+                const uint32_t packed = __builtin_amdgcn_readlane(e | (old << 8), w);
+                eqs = packed & 0xFFu; ref = packed >> 8;
+                more_eq = eqs == 9;
+            }
+            if (nlit) {
+                const uint32_t last = op + (nlit - 1) + (lit + nlit - 1) / kMaxLit;
+                if (last >= cap) { fail = true; break; }
+                if (lane < nlit) { // literal i = low byte of lane i
+                    const uint32_t t = lit + lane, p = op + lane + t / kMaxLit;
+                    out[p] = (uint8_t)v;
+                    if ((t + 1) % kMaxLit == 0) out[p - kMaxLit] = kMaxLit - 1;
+                }
+                op += nlit + (lit + nlit) / kMaxLit;
+                lit = (lit + nlit) % kMaxLit;
+                ip += nlit;
+            }
+            if (!mm) {
+                if (ip + 2 < n) vnext = request(ip);
+                continue;
+            }
+
+            // ---- match at ip against ref ----
+            uint32_t maxlen = n - ip - 2;
+            if (maxlen > kMaxRef) maxlen = kMaxRef;
+            if (op + 4 >= cap && op - (lit == 0) + 4 >= cap) { fail = true; break; }
+            if (lit) { if (lane == 0) out[op - lit - 1] = (uint8_t)(lit - 1); }
+            else op -= 1;
+            uint32_t eq = eqs;
+            {
+                const uint32_t room = (n - ip < kMaxRef + 2 ? n - ip : kMaxRef + 2) - 3;
+                if (eq >= room) { eq = room; more_eq = false; }
+            }
+            while (more_eq) {
+                const uint32_t t = 3 + eq + lane;
+                const bool ok = ip + t < n && t < kMaxRef + 2 && in[ref + t] == in[ip + t];
+                const uint32_t cnt = ctz64(~__ballot(ok));
+                eq += cnt;
+                if (cnt < 64) break;
+            }
+            uint32_t len;
+            if (maxlen > 16) {
+                if (eq < 16) len = 3 + eq;
+                else { len = 3 + eq < maxlen ? 3 + eq : maxlen; if (len < 19) len = 19; }
+            } else {
+                len = 3 + eq < maxlen ? 3 + eq : maxlen;
+                if (len < 3) len = 3;
+            }
+            const uint32_t off = ip - ref - 1, l2 = len - 2, at = op;
+            op += l2 < 7 ? 2 : 3;
+            lit = 0; op += 1;
+            // the inside of the match is never inserted (VERY_FAST re-inserts only its last two positions)
+            for (uint32_t i = lane; i + 3 < len; i += 64) {
+                const uint32_t q = ip + 1 + i;
+                atomicOr(reinterpret_cast<uint32_t *>(E) + (q >> 1), kSkipFlag << ((q & 1u) * 16));
+            }
+            ip += len;
+            const bool go_on = ip + 2 < n;
+            if (go_on) vnext = request(ip);
+            if (lane == 0) {
+                if (l2 < 7) {
+                    out[at] = (uint8_t)((off >> 8) + (l2 << 5));
+                    out[at + 1] = (uint8_t)off;
+                } else {
+                    out[at] = (uint8_t)((off >> 8) + (7u << 5));
+                    out[at + 1] = (uint8_t)(l2 - 7);
+                    out[at + 2] = (uint8_t)off;
+                }
+            }
+            if (!go_on) break;
+        }
+
+        if (!fail) {
+            if (op + 3 > cap) {
+                fail = true;
+            } else {
+                if (ip < n) put_literals(out, in, ip, n - ip, op, lit, lane);
+                if (lit) { if (lane == 0) out[op - lit - 1] = (uint8_t)(lit - 1); }
+                else op -= 1;
+            }
+        }
+        if (lane == 0) sizes[blk] = fail ? 0u : op;
+    }
+}
+
+namespace {
+struct LinkSpace { uint16_t *p = nullptr; size_t cap = 0; uint32_t *counter = nullptr; };
+std::mutex link_lock;
+std::unordered_map<hipStream_t, LinkSpace> link_map;
+}
+
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {
@@ -394,10 +637,61 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         attr_set = true;
     }
     const size_t grid = nblocks < 256 ? nblocks : 256; // the 128 KiB table admits one workgroup per CU
-    static const char *mode = getenv("CW_LZF_MODE"); // CW_LZF_MODE=cut: write/read-back kernel only (profiling knob)
-    const bool cut_only = mode && strcmp(mode, "cut") == 0;
+    // CW_LZF_MODE=cut: write/read-back kernel only; =table: exchange kernel with the 128 KiB table also for small blocks
+    static const char *mode = getenv("CW_LZF_MODE");
+    const bool cut_only = mode && strcmp(mode, "cut") == 0, table_only = mode && strcmp(mode, "table") == 0;
     static const char *redo_env = getenv("CW_LZ_FORCE_REDO"); // test knob, see lz4_kernel.hip
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
+    if (!cut_only && !table_only && n <= kChainMax && n >= 16) {
+        // small blocks: links for a chunk of blocks, then the chain parser over that chunk
+        const uint32_t n2 = (n + 63u) & ~63u;
+        const size_t chunk_max = ((size_t)256 << 20) / (2 * (size_t)n2); // 256 MiB of links per round
+        const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
+        LinkSpace ls;
+        {
+            std::lock_guard<std::mutex> g(link_lock);
+            LinkSpace &w = link_map[stream];
+            if (w.cap < chunk * n2) {
+                if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
+                w.p = nullptr; w.cap = 0;
+                hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.p), chunk * n2 * sizeof(uint16_t));
+                if (e != hipSuccess) return e;
+                w.cap = chunk * n2;
+            }
+            if (!w.counter) {
+                hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.counter), 64);
+                if (e != hipSuccess) return e;
+            }
+            ls = w;
+        }
+        static bool chain_attr = false;
+        if (!chain_attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_links_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_chain_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kChainMax + 256);
+            if (e != hipSuccess) return e;
+            chain_attr = true;
+        }
+        const uint32_t chain_lds = 2 * n2 + ((n + 15u) & ~15u) + 16u;
+        size_t per_cu = (160u * 1024u) / (chain_lds + 64);
+        if (per_cu > 16) per_cu = 16;
+        for (size_t first = 0; first < nblocks; first += chunk) {
+            const size_t nb = nblocks - first < chunk ? nblocks - first : chunk;
+            const uint8_t *s0 = src + first * src_stride;
+            hipError_t e = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), kLzfTabBytes, stream, s0, n, src_stride,
+                               nb, ls.p, n2, sizes + first, force_redo);
+            const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
+            hipLaunchKernelGGL(lzf_chain_kernel, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
+                               dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                           dst_stride, sizes, in_lds, 1u);
+        return hipGetLastError();
+    }
     if (!cut_only) {
         if (in_lds)
             hipLaunchKernelGGL(lzf_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
