@@ -388,12 +388,13 @@ lzf_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 //                      per exchange round, loads one round ahead)  writes link[] (u16 per position) to a workspace;
 //   lzf_chain_kernel  holds link[] + flags (2n bytes) and the block (n bytes) in LDS: 12.3 KiB per 4 KiB block.  There is no
 //                      table write during the parse, hence no rollback and no ordering assumption in this kernel;
-//                      lanes walk their chains in lockstep (one aligned u16 read per step), only kChainHead
-//                      positions per batch are speculated on so that the slowest chain of a batch stays short.
+//                      lanes walk their chains in lockstep (one aligned u16 read per step); a batch speculates on
+//                      kChainHead positions after a match (doubling while none is found) so that the slowest chain
+//                      of a batch stays short.
 // The lane-order check sits in lzf_links_kernel (a link >= its own position); a failing block is marked and parsed
 // by lzf_blocks_kernel like everywhere else.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kChainMax = 16384, kChainHead = 16, kSkipFlag = 0x8000u;
+constexpr uint32_t kChainMax = 16384, kChainHead = 8, kSkipFlag = 0x8000u;
 
 // 3 bytes at pos (as the low 24 bits) from global memory without reading past the block
 __device__ __forceinline__ uint32_t load3(const uint8_t *g, uint32_t n, uint32_t pos, bool ok)
@@ -407,26 +408,61 @@ __global__ void __launch_bounds__(64)
 lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint16_t *__restrict__ links,
                  uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo)
 {
+    // LDS: the 128 KiB table, then the block (coalesced copy; positions are then read as aligned dwords)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *stage = smem + kLzfTabBytes;
     const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(smem);
     const uint32_t lane = threadIdx.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0 && n <= 8192;
+    // the next block's bytes are requested while this block is linked (vec: up to 8 KiB in registers)
+    uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7; // named, not an array: hipcc put the array in scratch
+    pre0 = pre1 = pre2 = pre3 = pre4 = pre5 = pre6 = pre7 = make_uint4(0, 0, 0, 0);
+    // unconditional loads (a load inside a branch is waited for on the spot): past the block or the batch they
+    // re-read an in-range address and the value is never used
+#define CW_PRE1(K, G4, LAST) { const uint32_t i_ = 64 * K + lane; pre##K = (G4)[i_ <= (LAST) ? i_ : (LAST)]; }
+#define CW_PREFETCH(BLK)                                                                                   \
+    do {                                                                                                   \
+        const size_t b_ = (BLK) < nblocks ? (BLK) : nblocks - 1;                                           \
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(src + b_ * src_stride);                          \
+        const uint32_t last_ = (n - 1) / 16;                                                               \
+        CW_PRE1(0, g4, last_) CW_PRE1(1, g4, last_) CW_PRE1(2, g4, last_) CW_PRE1(3, g4, last_)            \
+        CW_PRE1(4, g4, last_) CW_PRE1(5, g4, last_) CW_PRE1(6, g4, last_) CW_PRE1(7, g4, last_)            \
+    } while (0)
+#define CW_STAGE1(K) if ((64 * K + lane) * 16 < n) reinterpret_cast<uint4 *>(stage)[64 * K + lane] = pre##K;
+    if (vec) CW_PREFETCH(blockIdx.x);
+
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const uint8_t *g = src + blk * src_stride;
         uint16_t *out = links + blk * (size_t)n2;
         __syncthreads();
-        for (uint32_t i = lane; i < kLzfTabBytes / 16; i += 64) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll 16
+        for (uint32_t i = 0; i < kLzfTabBytes / 16 / 64; i++) reinterpret_cast<uint4 *>(smem)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        if (vec) {
+            CW_STAGE1(0) CW_STAGE1(1) CW_STAGE1(2) CW_STAGE1(3) CW_STAGE1(4) CW_STAGE1(5) CW_STAGE1(6) CW_STAGE1(7)
+            CW_PREFETCH(blk + gridDim.x);
+        } else {
+            for (uint32_t i = lane; i < n; i += 64) stage[i] = g[i];
+        }
+        if (lane < 16) stage[((n + 15u) & ~15u) + lane] = 0; // slack read by the dword loads
         __syncthreads();
+
         bool bad = force_redo != 0;
-        uint32_t vn[4];
+        // the dwords around the positions of a round are read one round ahead, so that a round has ONE LDS wait
+        uint32_t lo[4], hi[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t pos = 64 * k + lane; vn[k] = load3(g, n, pos, pos + 2 < n); }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t pos = 64 * k + lane;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + ((pos + 2 < n ? pos : 0u) >> 2);
+            lo[k] = w[0]; hi[k] = w[1];
+        }
         for (uint32_t base = 0; base + 2 < n && !bad; base += 256) {
             uint32_t addr[4], mask[4], data[4], old[4], sh[4];
             bool ok[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t pos = base + 64 * k + lane, v = vn[k];
+                const uint32_t pos = base + 64 * k + lane;
                 ok[k] = pos + 2 < n;
+                const uint32_t v = __builtin_amdgcn_alignbyte(hi[k], lo[k], (ok[k] ? pos : 0u) & 3u);
                 const uint32_t slot = lzf_slot(v & 0xFFu, (v >> 8) & 0xFFu, (v >> 16) & 0xFFu);
                 sh[k] = (slot & 1u) * 16;
                 addr[k] = tab_lds + (slot >> 1) * 4;
@@ -434,7 +470,11 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 data[k] = ok[k] ? pos << sh[k] : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t pos = base + 256 + 64 * k + lane; vn[k] = load3(g, n, pos, pos + 2 < n); }
+            for (int k = 0; k < 4; k++) {
+                const uint32_t pos = base + 256 + 64 * k + lane;
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + ((pos + 2 < n ? pos : 0u) >> 2);
+                lo[k] = w[0]; hi[k] = w[1];
+            }
             // four exchanges back to back: the LDS runs them in order, lanes ascending inside each
             asm volatile("ds_mskor_rtn_b32 %0, %4, %8, %12\n\t"
                          "ds_mskor_rtn_b32 %1, %5, %9, %13\n\t"
@@ -453,9 +493,11 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 if (pos < n2) out[pos] = (uint16_t)o;
             }
         }
-        if (bad && lane == 0) sizes[blk] = kRedo;
-        else if (lane == 0) sizes[blk] = 0; // "links are valid" for lzf_chain_kernel
+        if (lane == 0) sizes[blk] = bad ? kRedo : 0u; // 0 = "links are valid" for lzf_chain_kernel
     }
+#undef CW_PREFETCH
+#undef CW_PRE1
+#undef CW_STAGE1
 }
 
 __global__ void __launch_bounds__(64)
@@ -496,10 +538,11 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             return lz::rd32x<true>(in, pos + 2 < n ? pos : 0u);
         };
         uint32_t vnext = fail ? 0u : request(0);
+        uint32_t head = kChainHead;
 
         while (!fail && ip + 2 < n) {
             const uint32_t pos = ip + lane;
-            const bool tested = lane < kChainHead && pos + 2 < n;
+            const bool tested = lane < head && pos + 2 < n;
             const uint32_t ntest = (uint32_t)__builtin_popcountll(__ballot(tested));
             const uint32_t v = vnext;
             // the reference the serial parser would read: first position on the link chain that was inserted
@@ -545,8 +588,10 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             }
             if (!mm) {
                 if (ip + 2 < n) vnext = request(ip);
+                head = head < 64 ? head * 2 : 64;
                 continue;
             }
+            head = kChainHead;
 
             // ---- match at ip against ref ----
             uint32_t maxlen = n - ip - 2;
@@ -667,7 +712,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         static bool chain_attr = false;
         if (!chain_attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_links_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kChainMax + 32);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_chain_kernel),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kChainMax + 256);
             if (e != hipSuccess) return e;
@@ -681,7 +726,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             const uint8_t *s0 = src + first * src_stride;
             hipError_t e = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), kLzfTabBytes, stream, s0, n, src_stride,
+            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), kLzfTabBytes + ((n + 15u) & ~15u) + 16u, stream, s0, n, src_stride,
                                nb, ls.p, n2, sizes + first, force_redo);
             const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
             hipLaunchKernelGGL(lzf_chain_kernel, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
