@@ -321,30 +321,47 @@ struct Walk { // progress of one block's no-match walk
     bool marked = false;
 };
 
+// NG batches of 64 probes: all ring reads, then all table exchanges, then all verdicts (so that the LDS round trips
+// of the batches overlap)
+template <int NG>
+__device__ __forceinline__ void probe_groups(Walk &w, const uint32_t (&pos)[kStreamGroup], const bool (&act)[kStreamGroup], uint32_t *tab,
+                                             const uint32_t *ring32, uint32_t tag, uint32_t epoch)
+{
+    uint32_t v[NG], old[NG];
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        // unaligned 4 bytes out of the ring: two aligned dwords (the second may wrap) + byte align; read
+        // unconditionally (any ring address is safe) so that the reads of the whole group pipeline
+        const uint32_t a0 = (pos[j] & (kRing - 1)) >> 2, a1 = (a0 + 1) & (kRing / 4 - 1);
+        v[j] = __builtin_amdgcn_alignbyte(ring32[a1], ring32[a0], pos[j] & 3u);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; j++) old[j] = scan_issue(tab, tag, pos[j], v[j], act[j]);
+#pragma unroll
+    for (int j = 0; j < NG; j++) scan_judge(old[j], epoch, w.v0, pos[j], v[j], act[j], w.st);
+}
+
 // run every probe whose position is < end (their bytes, incl. a straddle of up to 3, are in the ring)
 __device__ __forceinline__ void probe_upto(Walk &w, uint32_t end, uint32_t *tab, const uint32_t *ring32, uint32_t tag, uint32_t epoch,
                                            uint32_t nprobes, const uint8_t *g, uint32_t lane)
 {
     for (;;) {
-        uint32_t pos[kStreamGroup], v[kStreamGroup], nact = 0;
+        uint32_t pos[kStreamGroup], nact = 0, ngroups = 0;
         bool act[kStreamGroup];
 #pragma unroll
         for (uint32_t j = 0; j < kStreamGroup; j++) {
             const uint32_t k = w.knext + 64 * j + lane;
             pos[j] = 1 + probe_delta(k);
             act[j] = k < nprobes && pos[j] < end;
-            // unaligned 4 bytes out of the ring: two aligned dwords (the second may wrap) + byte align; read
-            // unconditionally (any ring address is safe) so that the reads of the whole group pipeline
-            const uint32_t a0 = (pos[j] & (kRing - 1)) >> 2, a1 = (a0 + 1) & (kRing / 4 - 1);
-            v[j] = __builtin_amdgcn_alignbyte(ring32[a1], ring32[a0], pos[j] & 3u);
-            nact += (uint32_t)__builtin_popcountll(__ballot(act[j]));
+            const unsigned long long m = __ballot(act[j]);
+            nact += (uint32_t)__builtin_popcountll(m);
+            ngroups += m != 0; // probes ascend with k: the batches that have any form a prefix
         }
         if (nact == 0) return;
-        uint32_t old[kStreamGroup];
-#pragma unroll
-        for (uint32_t j = 0; j < kStreamGroup; j++) old[j] = scan_issue(tab, tag, pos[j], v[j], act[j]);
-#pragma unroll
-        for (uint32_t j = 0; j < kStreamGroup; j++) scan_judge(old[j], epoch, w.v0, pos[j], v[j], act[j], w.st);
+        // late chunks hold fewer than 128 probes (the parser's step has grown): do not run empty batches
+        if (ngroups == 1) probe_groups<1>(w, pos, act, tab, ring32, tag, epoch);
+        else if (ngroups == 2) probe_groups<2>(w, pos, act, tab, ring32, tag, epoch);
+        else probe_groups<kStreamGroup>(w, pos, act, tab, ring32, tag, epoch);
         w.marked = scan_settle(g, w.st);
         w.knext += nact;
         if (w.marked || nact < 64 * kStreamGroup) return;
