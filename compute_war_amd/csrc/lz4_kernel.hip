@@ -280,7 +280,7 @@ lz4_scan_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
 // hit, so compressible data costs a chunk or two of reads and at most one chunk of wasted stores here.
 // LDS: 32 KiB table + 8 KiB ring = 40 KiB -> 4 wavefronts per CU.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kChunk = 4096, kPieces = kChunk / 1024, kRing = 2 * kChunk, kStreamGroup = 4;
+constexpr uint32_t kChunk = 4096, kPieces = kChunk / 1024, kRing = 2 * kChunk, kStreamGroup = 2;
 
 struct Chunk { uint4 p[kPieces]; }; // 4 KiB of the block across the wavefront: piece j, lane L = bytes [j*1024 + L*16, +16)
 
