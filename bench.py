@@ -196,7 +196,8 @@ def main():
     alg_bytes = {"hash": bs + db, "comp": bs + csize + 4}
     names = {"hash": {"skein512": "cw::skein_lines_kernel<8,true>", "skein": "cw::skein_lines_kernel<4,true>",
                       "sha256mb": "cw::sha256_blocks_kernel<true,false>"}[args.hash],
-             "comp": "cw::lz4_scan_kernel (+ cw::lz4_blocks_kernel on queued blocks)" if args.comp == "lz4" else "cw::lzf_blocks_kernel"}
+             "comp": "cw::lz4_scan_stream_kernel (+ cw::lz4_parse_kernel on queued blocks)" if args.comp == "lz4"
+                     else "cw::lzf_links_kernel + cw::lzf_chain_kernel" if bs <= 16384 else "cw::lzf_parse_kernel"}
     dom = max(k_ms, key=k_ms.get)
     kernels = {k: {"ms_per_launch": round(k_ms[k], 3),
                    "alg_GBps": round(alg_bytes[k] * nb / (k_ms[k] / 1e3) / 1e9, 1),
@@ -221,6 +222,12 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "alg_bytes_per_block": round(alg_bytes[dom], 1)},
         "kernels": dict(kernels, note="codec and hash run concurrently on two streams; durations overlap"),
+        # the binding roof of the hash kernel is integer VALU issue, not HBM: instruction mix of one
+        # Threefish-512 call x measured per-instruction cost = 2.65 us per wavefront-call per SIMD
+        "valu_roofline": ({"kernel": names["hash"], "achieved": round(bs * nb / (k_ms["hash"] / 1e3) / 1e9, 1), "peak": 1580.0,
+                           "unit": "GB/s", "frac": round(bs * nb / (k_ms["hash"] / 1e3) / 1e9 / 1580.0, 4),
+                           "note": "peak = 1024 SIMDs x 4096 B per wavefront-call / 2.65 us; shared with the codec's VALU work "
+                                   "when both kernels run"} if args.hash == "skein512" else None),
         "parity_spot_check": spot,
     }
     if world == 1 and not args.no_cpu_baseline:
