@@ -371,7 +371,7 @@ __device__ __forceinline__ void probe_upto(Walk &w, uint32_t end, uint32_t *tab,
 __global__ void __launch_bounds__(64)
 lz4_scan_stream_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
                        uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nprobes,
-                       uint32_t *__restrict__ queue, uint32_t *__restrict__ counters)
+                       uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, size_t first_block, uint32_t feed_word)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
     __shared__ __attribute__((aligned(16))) uint32_t ring32[kRing / 4];
@@ -384,7 +384,9 @@ lz4_scan_stream_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_s
 
     BlockFeed feed;
     const uint32_t run = n >= 65536 ? 1u : 65536u / n; // blocks per pull
-    for (size_t blk; scan_next_block(feed, blk, counters, mailbox, run, nblocks, lane);) {
+    // blocks [first_block, nblocks): the span kernel may have taken the blocks in front; feed counter = counters[feed_word]
+    for (size_t rel; scan_next_block(feed, rel, counters + feed_word - 2, mailbox, run, nblocks - first_block, lane);) {
+        const size_t blk = first_block + rel;
         scan_begin_block(tab, epoch, lane);
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride, *lit = out + hdr;
@@ -441,6 +443,132 @@ lz4_scan_stream_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_s
             out[0] = (uint8_t)(n << 4);
         }
         if (lane == 0) sizes[blk] = hdr + n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Span scan: the streaming scan for power-of-two block sizes 4 KiB .. 64 KiB, written so that hipcc can count its
+// memory operations.  In lz4_scan_stream_kernel every chunk load/store sits in a bounds branch ("off < n"), and
+// hipcc answers a load inside a branch with s_waitcnt vmcnt(0) at the next use of ANY loaded value: the wait in
+// front of staging chunk c also waited for the loads of chunk c+2 issued a few instructions earlier, so nothing was
+// ever in flight across a stage.  Here a wavefront pulls a SPAN of 16 chunks = 64 KiB (one 64 KiB block, or 16
+// consecutive 4 KiB blocks, ...): every chunk is full, every load and store is unconditional (the two loads past the
+// span re-read its last chunk), the chunk pipeline runs across the block boundaries inside a span (so 4 KiB blocks
+// are pipelined at all), and the waits come out as vmcnt(N) with the next chunks still in flight.
+// Step i: store chunk i-1 (speculatively, as before), load chunk i+2 into the registers that frees, finish the
+// previous block if chunk i starts a new one, stage chunk i in the LDS ring, probe the positions below it.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+lz4_scan_span_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint32_t nspans, uint8_t *__restrict__ dst,
+                     size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nprobes, uint32_t *__restrict__ queue,
+                     uint32_t *__restrict__ counters, uint32_t lg)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
+    __shared__ __attribute__((aligned(16))) uint32_t ring32[kRing / 4];
+    volatile uint32_t *mailbox = ring32; // free between two spans
+    const uint32_t lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t epoch = 15;
+    const uint32_t cmask = (1u << lg) - 1, run = 16u >> lg; // chunks per block - 1, blocks per span
+    const uint32_t hdr = 1 + (n - 15) / 255 + 1;            // token + length bytes of the single literal run (n >= 4096)
+    const uint32_t lane16 = lane * 16;
+
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) *mailbox = atomicAdd(&counters[2], 1u);
+        __syncthreads();
+        const uint32_t span = __builtin_amdgcn_readfirstlane(*mailbox);
+        if (span >= nspans) break;
+        __syncthreads(); // the mailbox word is ring memory
+        const size_t first = (size_t)span * run;
+        const uint8_t *gs = src + first * src_stride;
+        uint8_t *os = dst + first * dst_stride + hdr;
+
+        Walk w;
+        size_t blk = first;
+        uint32_t tag = 0;
+        Chunk r0, r1, r2;
+#define CW_LD(R, I)                                                                                          \
+        do {                                                                                                 \
+            const uint32_t i_ = (I) < 15u ? (I) : 15u;                                                       \
+            const uint8_t *p_ = gs + (size_t)(i_ >> lg) * src_stride + ((i_ & cmask) << 12) + lane16;        \
+            _Pragma("unroll") for (uint32_t j = 0; j < kPieces; j++) R.p[j] = *reinterpret_cast<const uint4 *>(p_ + j * 1024); \
+        } while (0)
+#define CW_ST(R, I)                                                                                          \
+        do {                                                                                                 \
+            const uint32_t i_ = (I);                                                                         \
+            uint8_t *p_ = os + (size_t)(i_ >> lg) * dst_stride + ((i_ & cmask) << 12) + lane16;              \
+            _Pragma("unroll") for (uint32_t j = 0; j < kPieces; j++) {                                       \
+                uint32_t *q = reinterpret_cast<uint32_t *>(p_ + j * 1024); /* 2-byte-misaligned: 4 dword stores, merged by hipcc */ \
+                __builtin_nontemporal_store(R.p[j].x, q);     __builtin_nontemporal_store(R.p[j].y, q + 1);  \
+                __builtin_nontemporal_store(R.p[j].z, q + 2); __builtin_nontemporal_store(R.p[j].w, q + 3);  \
+            }                                                                                                \
+        } while (0)
+#define CW_FINISH()                                                                                          \
+        do { /* the block's last probes (nothing straddles its end), then its verdict */                     \
+            if (!w.marked) probe_upto(w, n, tab, ring32, tag, epoch, nprobes, src + blk * src_stride, lane); \
+            if (w.marked) scan_mark(sizes, blk, queue, counters, lane);                                      \
+            else {                                                                                           \
+                uint8_t *out = dst + blk * dst_stride;                                                       \
+                if (lane == 0) out[0] = 15u << 4;                                                            \
+                put_len(out + 1, n - 15, lane);                                                              \
+                if (lane == 0) sizes[blk] = hdr + n;                                                         \
+            }                                                                                                \
+        } while (0)
+#define CW_BEGIN(I)                                                                                          \
+        do {                                                                                                 \
+            blk = first + ((I) >> lg);                                                                       \
+            scan_begin_block(tab, epoch, lane);                                                              \
+            tag = epoch << 28;                                                                               \
+            w = Walk();                                                                                      \
+        } while (0)
+#define CW_STAGE_IN(R, C)                                                                                    \
+        do {                                                                                                 \
+            uint8_t *p_ = reinterpret_cast<uint8_t *>(ring32) + (((C) & 1u) << 12) + lane16;                 \
+            _Pragma("unroll") for (uint32_t j = 0; j < kPieces; j++) *reinterpret_cast<uint4 *>(p_ + j * 1024) = R.p[j]; \
+        } while (0)
+#define CW_AFTER_STAGE(C)                                                                                    \
+        do {                                                                                                 \
+            if ((C) == 0) {                                                                                  \
+                w.v0 = ring32[0];                                                                            \
+                if (nprobes && lane == 0) {                                                                  \
+                    const uint32_t h0 = w.v0 * 2654435761u;                                                  \
+                    atomicMax(&tab[h0 >> 19], tag | ((h0 >> 7) & 0xFFFu)); /* position 0 */                  \
+                }                                                                                            \
+            } else if (!w.marked) {                                                                          \
+                probe_upto(w, (C) * kChunk, tab, ring32, tag, epoch, nprobes, src + blk * src_stride, lane); \
+            }                                                                                                \
+        } while (0)
+#define CW_STEP(PREV, CUR, I)                                                                                \
+        do {                                                                                                 \
+            const uint32_t s_ = (I), c_ = s_ & cmask;                                                        \
+            CW_ST(PREV, s_ - 1);                                                                             \
+            CW_LD(PREV, s_ + 2);                                                                             \
+            if (c_ == 0) { CW_FINISH(); CW_BEGIN(s_); }                                                      \
+            CW_STAGE_IN(CUR, c_);                                                                            \
+            CW_AFTER_STAGE(c_);                                                                              \
+        } while (0)
+
+        CW_LD(r0, 0u);
+        CW_LD(r1, 1u);
+        CW_LD(r2, 2u);
+        CW_BEGIN(0u);
+        CW_STAGE_IN(r0, 0u);
+        CW_AFTER_STAGE(0u);
+        for (uint32_t i = 1; i < 16; i += 3) {
+            CW_STEP(r0, r1, i);
+            CW_STEP(r1, r2, i + 1);
+            CW_STEP(r2, r0, i + 2);
+        }
+        CW_ST(r0, 15u);
+        CW_FINISH();
+#undef CW_LD
+#undef CW_ST
+#undef CW_FINISH
+#undef CW_BEGIN
+#undef CW_STAGE_IN
+#undef CW_AFTER_STAGE
+#undef CW_STEP
     }
 }
 
@@ -955,9 +1083,24 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (streamable) {
         static const char *wpc_env = getenv("CW_SCAN_WPC"); // scan wavefronts per CU (profiling knob; 4 = all that fit)
         const size_t wpc = wpc_env && atoi(wpc_env) > 0 ? (size_t)atoi(wpc_env) : 4;
-        const size_t sgrid = nblocks < 256 * wpc ? nblocks : 256 * wpc; // 40 KiB of LDS each -> at most 4 per CU
-        hipLaunchKernelGGL(lz4_scan_stream_kernel, dim3((unsigned)sgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
-                           dst_stride, sizes, scan_probes(n), queue, counters);
+        // power-of-two sizes 4 KiB .. 64 KiB go through the span kernel, 64 KiB of whole blocks per pull; what does not
+        // fill a span (and every other size) through the per-block streaming kernel.  CW_LZ4_MODE=stream: the latter only.
+        const bool pow2 = n >= kChunk && (n & (n - 1)) == 0 && !(mode && strcmp(mode, "stream") == 0);
+        uint32_t lg = 0;
+        while (pow2 && (kChunk << lg) < n) lg++;
+        const size_t run = pow2 ? (size_t)(16u >> lg) : 1;
+        const size_t nspans = pow2 ? nblocks / run : 0, done = nspans * run;
+        if (nspans) {
+            const size_t g = nspans < 256 * wpc ? nspans : 256 * wpc; // 40 KiB of LDS each -> at most 4 per CU
+            hipLaunchKernelGGL(lz4_scan_span_kernel, dim3((unsigned)g), dim3(64), 0, stream, src, n, src_stride, (uint32_t)nspans, dst,
+                               dst_stride, sizes, scan_probes(n), queue, counters, lg);
+        }
+        if (done < nblocks) {
+            const size_t rest = nblocks - done;
+            const size_t sgrid = rest < 256 * wpc ? rest : 256 * wpc;
+            hipLaunchKernelGGL(lz4_scan_stream_kernel, dim3((unsigned)sgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, scan_probes(n), queue, counters, done, 3u);
+        }
     } else {
         hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, scan_probes(n), queue, counters);
