@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--comp", default="lz4", choices=["lz4", "lzf"])
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--standalone", action="store_true",
+                    help="after the timed region also launch each kernel alone (3x) and report its own roofline; off by default so "
+                         "that a rocprofv3 summary of the default command holds fused launches only")
     return ap.parse_args()
 
 
@@ -166,6 +169,23 @@ def main():
 
     prof = cw.profile_read(reset=True)
     k_ms = {"comp": prof["codec"][0] / max(prof["codec"][1], 1), "hash": prof["hash"][0] / max(prof["hash"][1], 1)}
+
+    # outside the timed region: each kernel on its own (3 launches), for the per-kernel rooflines
+    solo_ms = {}
+    cw.profile_enable(args.standalone)
+    for _ in range(3 if args.standalone else 0):
+        cw.dev_compress(args.comp, src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s)
+    torch.cuda.synchronize()
+    p2 = cw.profile_read(reset=True)
+    solo_ms["comp"] = p2["codec"][0] / max(p2["codec"][1], 1)
+    for _ in range(3 if args.standalone else 0):
+        cw.dev_hash(args.hash, src.data_ptr(), bs, nb, dig_bufs[0].data_ptr(), s)
+    torch.cuda.synchronize()
+    p2 = cw.profile_read(reset=True)
+    solo_ms["hash"] = p2["hash"][0] / max(p2["hash"][1], 1)
+    cw.profile_enable(False)
+    if not args.standalone:
+        solo_ms = {}
     total_blocks = nb * world
     bytes_out = int(all_totals[0].item())
     value = total_blocks * bs * args.steps / elapsed / 1e9
@@ -228,6 +248,10 @@ def main():
                            "unit": "GB/s", "frac": round(bs * nb / (k_ms["hash"] / 1e3) / 1e9 / 1580.0, 4),
                            "note": "peak = 1024 SIMDs x 4096 B per wavefront-call / 2.65 us; shared with the codec's VALU work "
                                    "when both kernels run"} if args.hash == "skein512" else None),
+        # each kernel launched alone (not part of `value`): algorithmic bytes / duration against the HBM peak
+        "standalone": {k: {"ms_per_launch": round(solo_ms[k], 3), "ingest_GBps": round(bs * nb / (solo_ms[k] / 1e3) / 1e9, 1),
+                           "alg_GBps": round(alg_bytes[k] * nb / (solo_ms[k] / 1e3) / 1e9, 1),
+                           "hbm_frac": round(alg_bytes[k] * nb / (solo_ms[k] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)} for k in solo_ms},
         "parity_spot_check": spot,
     }
     if world == 1 and not args.no_cpu_baseline:
