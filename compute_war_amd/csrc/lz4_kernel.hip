@@ -7,27 +7,24 @@
 // reference's 4 KiB blocks (and the 64 KiB north-star blocks) ever enter.  The parser's semantics are
 // those written down in SURVEY.md 8(a) row A5 and restated on the CPU in oracle/lz4_oracle.c.
 //
-// Mapping to the machine.  The parse is a serial greedy walk over one mutable hash table, so the unit
-// of parallelism is the block: a 64-lane wavefront owns one block, holds its 8192 x u16 table (and, for
-// blocks up to 16 KiB, the block itself) in LDS, and uses its lanes for the parts that are parallel
-// inside a block:
-//   * the search loop: while no match is found the positions the serial parser will probe do not
-//     depend on the table (only the skip schedule), so lane j speculatively runs probe k0+j; a
-//     ballot picks the first lane whose candidate matches; table writes are committed only for lanes
-//     up to and including it.  Two lanes hitting one table slot inside a batch are detected by a
-//     write/read-back and the batch is cut in front of the first such lane, so every committed lane
-//     saw exactly the table the serial parser would have shown it;
-//   * backward/forward match extension: 64 byte compares per step, ballot + count-trailing-ones;
-//   * literal copies and length-byte runs: 16 B per lane, 1 KiB per wavefront instruction.
+// Mapping to the machine.  The parse is a serial greedy walk over one mutable hash table, so the unit of
+// parallelism is the block: a 64-lane wavefront owns one block and its 8192 x u16 table in LDS, and uses its lanes
+// for what is parallel inside a block -- the probes of a search (their positions depend only on the skip schedule,
+// lane j runs probe j), match extension (byte compares + ballot), literal and length-byte stores.
 // Output goes straight to the block's slot in HBM (dst + i*dst_stride); sizes[i] receives the length.
 //
-// Two kernels per call.  (1) lz4_scan_kernel runs, for every block, exactly the probe sequence the serial
-// parser performs while it finds NO match (positions depend only on the skip schedule).  If no probe's
-// candidate matches, the parser's output is fully determined -- one literal run -- and the scan kernel
-// writes it and is done with the block: that is every incompressible block, at a small fraction of the
-// cost of a real parse and with only the table (no block copy) in LDS, i.e. 5 instead of 2 blocks per CU.
-// The first matching probe instead marks the block (sizes[i] = kNeedsParse).  (2) lz4_blocks_kernel
-// parses the marked blocks with the full machinery above.  Both produce the serial parser's bytes.
+// Kernels, in launch order (DESIGN.md 4.3 has the measurements):
+//   1. scan   -- for every block the probe sequence the serial parser performs while it finds NO match.  No probe
+//                matched => the output is one literal run, written here (every incompressible block, at HBM speed);
+//                first hit => the block index is queued.  lz4_scan_span_kernel (power-of-two sizes 4..64 KiB, 64 KiB
+//                spans, straight-line memory operations), lz4_scan_stream_kernel (other aligned sizes and span
+//                tails), lz4_scan_kernel (unaligned: gathers).
+//   2. parse  -- lz4_parse_kernel: full parse of the queued blocks; the table operation of a batch of items is one
+//                ds_mskor_rtn_b32 exchange whose lanes the LDS applies in ascending order (verified per batch).
+//   3. redo   -- lz4_blocks_kernel: the first-generation parser (write/read-back collision detection, batch cut,
+//                rollback), run on the blocks the parse kernel hands back when its lane-order check fails (never
+//                observed; forced in the tests).
+// All of them produce the serial parser's bytes.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -7,16 +7,21 @@
 // src/compression_perf/include/lzf/lzf.h:79-81).  Semantics are those of SURVEY.md 8(a) row A6 as restated on the
 // CPU in oracle/lzf_oracle.c, with the hash table taken as zero-initialised (hard part 4).
 //
-// Mapping to the machine.  Like LZ4 the parse is a serial walk over a mutable hash table -- here 65,536 slots
-// that see EVERY position -- so a wavefront owns one block and its table (65,536 x u16 = 128 KiB of LDS: one
-// block per CU; blocks up to 16 KiB also keep their bytes in LDS).  Lane j speculatively handles position ip+j
-// (hash the 3 bytes, read the slot, write the slot); a write/read-back finds lanes whose slot another lane of
-// the batch overwrote and the batch is cut in front of the first of them, so every committed lane saw the
-// table the serial parser would have shown it; the first lane whose candidate passes the parser's match test
-// ends the batch, later lanes' table writes are rolled back, the lanes before it become literals (run
-// control bytes placed by closed form), and match extension / emission are done wave-wide.
-// The reference's out_len = l - 1 makes incompressible blocks return 0; every one of the parser's overflow
-// checks is reproduced, so that verdict is exact too.
+// Mapping to the machine.  Like LZ4 the parse is a serial walk over a mutable hash table -- here 65,536 slots that
+// see EVERY position -- so a wavefront owns one block; lane j speculatively handles position ip+j, the first lane
+// whose reference passes the parser's match test ends the batch, the lanes before it become literals (run control
+// bytes placed by closed form), match extension / emission are done wave-wide.  The reference's out_len = l - 1
+// makes incompressible blocks return 0; every one of the parser's overflow checks is reproduced, so that verdict
+// is exact too.
+//
+// Kernels (DESIGN.md 4.4 has the measurements):
+//   blocks <= 16 KiB:  lzf_links_kernel (per-position "previous position with my slot", 128 KiB table, throughput
+//                      bound) + lzf_chain_kernel (parse on link chains + skip flags: 12.3 KiB of LDS per 4 KiB block,
+//                      13 blocks per CU, no table writes);
+//   larger blocks:     lzf_parse_kernel (128 KiB table in LDS, one block per CU; table operation of a batch = one
+//                      ds_mskor_rtn_b32 exchange, lanes in ascending order, verified per batch);
+//   redo:              lzf_blocks_kernel, the first-generation parser (write/read-back collision detection, batch
+//                      cut, rollback) for blocks whose lane-order check failed (never observed; forced in the tests).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
