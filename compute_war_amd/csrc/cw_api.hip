@@ -242,6 +242,9 @@ void cw_shutdown(void)
     std::lock_guard<std::mutex> g(g_lock);
     if (g_device.load() < 0) return;
     (void)hipDeviceSynchronize();
+    cw::lz4_release_workspaces();
+    cw::lzf_release_workspaces();
+    cw::pack_release_workspaces();
     g_device.store(-1);
 }
 

@@ -34,6 +34,10 @@ hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, c
 // packed stream: offsets[i] = sum sizes[0..i) (nblocks + 1 entries); slot i copied to packed + offsets[i] (packed may be NULL)
 hipError_t pack_launch(const uint8_t *slots, size_t slot_stride, const uint32_t *sizes, size_t nblocks, uint8_t *packed,
                        uint64_t *offsets, hipStream_t stream);
+// per-stream scratch of the codec / pack launches (queues, link arrays, scan partials): freed by cw_shutdown
+void lz4_release_workspaces();
+void lzf_release_workspaces();
+void pack_release_workspaces();
 hipError_t sum_sizes_launch(const uint32_t *sizes, size_t n, uint32_t raw_bytes, uint64_t *totals, hipStream_t stream);
 hipError_t gen_random_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
                              hipStream_t stream);

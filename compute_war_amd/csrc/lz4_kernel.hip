@@ -1045,6 +1045,13 @@ hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out, siz
 }
 } // namespace
 
+void lz4_release_workspaces()
+{
+    std::lock_guard<std::mutex> g(ws_lock);
+    for (auto &kv : ws_map) if (kv.second.p) (void)hipFree(kv.second.p);
+    ws_map.clear();
+}
+
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {

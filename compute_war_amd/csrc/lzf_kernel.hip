@@ -667,6 +667,16 @@ std::mutex link_lock;
 std::unordered_map<hipStream_t, LinkSpace> link_map;
 }
 
+void lzf_release_workspaces()
+{
+    std::lock_guard<std::mutex> g(link_lock);
+    for (auto &kv : link_map) {
+        if (kv.second.p) (void)hipFree(kv.second.p);
+        if (kv.second.counter) (void)hipFree(kv.second.counter);
+    }
+    link_map.clear();
+}
+
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {

@@ -114,6 +114,13 @@ std::unordered_map<hipStream_t, Workspace> ws_map;
 
 } // namespace
 
+void pack_release_workspaces()
+{
+    std::lock_guard<std::mutex> g(ws_lock);
+    for (auto &kv : ws_map) if (kv.second.p) (void)hipFree(kv.second.p);
+    ws_map.clear();
+}
+
 hipError_t pack_launch(const uint8_t *slots, size_t slot_stride, const uint32_t *sizes, size_t nblocks, uint8_t *packed,
                        uint64_t *offsets, hipStream_t stream)
 {
