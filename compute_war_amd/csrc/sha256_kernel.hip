@@ -25,6 +25,8 @@ __constant__ uint32_t K256[64] = {
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
 static __device__ __forceinline__ uint32_t rotr(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, r); }
+// a ^ b ^ c in one v_bitop3_b32 (truth table 0x96); hipcc emits two v_xor_b32 for the plain expression
+static __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
 // one 64-byte compression; w[] holds the 16 big-endian message words and is consumed as the rolling schedule
 static __device__ __forceinline__ void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16])
@@ -34,14 +36,14 @@ static __device__ __forceinline__ void sha256_compress(uint32_t (&h)[8], uint32_
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
             const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-            const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+            const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
         const uint32_t ch = (e & f) | (~e & g);
         const uint32_t t1 = hh + S1 + ch + K256[i] + w[i & 15];
-        const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
         const uint32_t mj = (a & b) | (c & (a | b));
         const uint32_t t2 = S0 + mj;
         hh = g; g = f; f = e; e = d + t1;
