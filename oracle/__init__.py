@@ -40,6 +40,8 @@ def lib() -> C.CDLL:
         L.cw_oracle_skein512.argtypes = [u8p, C.c_size_t, C.c_uint, u8p]
         L.cw_oracle_skein256.argtypes = [u8p, C.c_size_t, C.c_uint, u8p]
         L.cw_oracle_skein_iv.argtypes = [C.c_int, C.c_uint, u8p]
+        L.cw_oracle_skein_tree.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint, u8p]
+        L.cw_oracle_skein_tree.restype = C.c_int
         L.cw_oracle_sha256.argtypes = [u8p, C.c_size_t, u8p]
         for f in (L.cw_oracle_lz4_compress, L.cw_oracle_lzf_compress):
             f.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t]
@@ -79,6 +81,16 @@ def skein256(data, hash_bits: int = 128, msg_bits: int | None = None) -> bytes:
     a = _buf(data)
     out = np.zeros((hash_bits + 7) // 8, dtype=np.uint8)
     lib().cw_oracle_skein256(_ptr(a), a.size * 8 if msg_bits is None else msg_bits, hash_bits, _ptr(out))
+    return out.tobytes()
+
+
+def skein_tree(state_bits: int, data, hash_bits: int, leaf: int, node: int, max_level: int) -> bytes:
+    """Skein tree hashing (skein_test.c:616-680): state_bits 256 or 512, byte-granular message."""
+    a = _buf(data)
+    out = np.zeros((hash_bits + 7) // 8, dtype=np.uint8)
+    rc = lib().cw_oracle_skein_tree(state_bits // 64, _ptr(a), a.size, hash_bits, leaf, node, max_level, _ptr(out))
+    if rc != 0:
+        raise ValueError("bad tree parameters")
     return out.tobytes()
 
 

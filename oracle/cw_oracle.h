@@ -35,6 +35,9 @@ int cw_oracle_skein512(const uint8_t *msg, size_t msg_bits, unsigned hash_bits, 
 int cw_oracle_skein256(const uint8_t *msg, size_t msg_bits, unsigned hash_bits, uint8_t *out);
 /* initial chaining value for (state words, hash_bits): the config-block UBI */
 void cw_oracle_skein_iv(int state_words, unsigned hash_bits, uint64_t *iv);
+/* tree hashing, follows reference_code/skein/Additional_Implementations/skein_test.c:616-680 (state_words 4 or 8) */
+int cw_oracle_skein_tree(int state_words, const uint8_t *msg, size_t len, unsigned hash_bits, unsigned leaf, unsigned node,
+                         unsigned max_level, uint8_t *out);
 
 /* ---- SHA-256 (FIPS 180-4) ---------------------------------------------- */
 void cw_oracle_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);

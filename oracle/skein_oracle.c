@@ -14,6 +14,7 @@
  * against oracle/_ref/libskein_ref.so (the reference's own C compiled in place).
  */
 #include "cw_oracle.h"
+#include <stdlib.h>
 #include <string.h>
 
 #define T1_FIRST   (1ULL << 62)
@@ -83,10 +84,10 @@ static void ubi_block(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const u
     for (i = 0; i < nw; i++) chain[i] = v[i] ^ w[i];
 }
 
-void cw_oracle_skein_iv(int nw, unsigned hash_bits, uint64_t *iv)
+static void skein_iv_tree(int nw, unsigned hash_bits, uint64_t tree_info, uint64_t *iv)
 {
     uint8_t cfg[64];
-    uint64_t words[3] = {SCHEMA_VER, hash_bits, 0 /* sequential, no tree */};
+    uint64_t words[3] = {SCHEMA_VER, hash_bits, tree_info /* 0 = sequential; leaf | node << 8 | maxLevel << 16 (skein.h:209-210) */};
     memset(cfg, 0, sizeof cfg);
     for (int k = 0; k < 3; k++)
         for (int b = 0; b < 8; b++) cfg[8 * k + b] = (uint8_t)(words[k] >> (8 * b));
@@ -94,6 +95,8 @@ void cw_oracle_skein_iv(int nw, unsigned hash_bits, uint64_t *iv)
     /* config string is 32 bytes whatever the state size (skein.h SKEIN_CFG_STR_LEN) */
     ubi_block(nw, iv, 32, T1_FIRST | T1_FINAL | T1_TYPE(TYPE_CFG), cfg);
 }
+
+void cw_oracle_skein_iv(int nw, unsigned hash_bits, uint64_t *iv) { skein_iv_tree(nw, hash_bits, 0, iv); }
 
 static int skein_generic(int nw, const uint8_t *msg, size_t msg_bits, unsigned hash_bits, uint8_t *out)
 {
@@ -150,4 +153,86 @@ int cw_oracle_skein512(const uint8_t *msg, size_t msg_bits, unsigned hash_bits, 
 int cw_oracle_skein256(const uint8_t *msg, size_t msg_bits, unsigned hash_bits, uint8_t *out)
 {
     return skein_generic(4, msg, msg_bits, hash_bits, out);
+}
+
+/*
+ * Tree hashing.  Follows the reference's all-in-one Skein_TreeHash
+ * (reference_code/skein/Additional_Implementations/skein_test.c:616-680; tree fields of the configuration block
+ * skein.h:209-210, tree level in the tweak skein.h:148,161,241): leaves of blkBytes << leaf bytes are hashed as
+ * independent UBI chains that start from the configuration result G with the leaf's byte offset as the initial
+ * tweak position and tree level 1; their outputs are concatenated and hashed again in nodes of blkBytes << node
+ * bytes at level 2, and so on, until one block is left -- or until level maxLevel, which hashes whatever is left in
+ * one chain.  The output transform is applied to the last chaining value.  Byte-granular messages only.
+ */
+static void ubi_chain(int nw, uint64_t *chain, const uint64_t *g, const uint8_t *data, size_t n, uint64_t t0, unsigned level)
+{
+    const size_t bb = (size_t)nw * 8;
+    uint64_t t1 = T1_FIRST | T1_TYPE(TYPE_MSG) | ((uint64_t)level << 48); /* level: tweak bits 112..118 */
+    uint8_t last[64];
+    size_t pos = 0, rem;
+    memcpy(chain, g, sizeof(uint64_t) * (size_t)nw);
+    while (n - pos > bb) {
+        t0 += bb;
+        ubi_block(nw, chain, t0, t1, data + pos);
+        t1 &= ~T1_FIRST;
+        pos += bb;
+    }
+    rem = n - pos;
+    memset(last, 0, sizeof last);
+    if (rem) memcpy(last, data + pos, rem);
+    ubi_block(nw, chain, t0 + rem, t1 | T1_FINAL, last);
+}
+
+int cw_oracle_skein_tree(int nw, const uint8_t *msg, size_t len, unsigned hash_bits, unsigned leaf, unsigned node,
+                         unsigned max_level, uint8_t *out)
+{
+    const size_t bb = (size_t)nw * 8;
+    uint64_t g[8], s[8] = {0};
+    size_t bcnt = len, cap = len + bb;
+    uint8_t *m;
+    unsigned height, out_bytes = (hash_bits + 7) >> 3, produced = 0;
+    uint64_t ctr = 0;
+    if ((nw != 4 && nw != 8) || hash_bits == 0 || leaf == 0 || node == 0 || max_level < 2 || leaf > 255 || node > 255 || max_level > 255)
+        return -1;
+    if (leaf > 40 || node > 40) return -1; /* shifts below */
+    m = (uint8_t *)malloc(cap);
+    if (!m) return -1;
+    if (len) memcpy(m, msg, len);
+    skein_iv_tree(nw, hash_bits, (uint64_t)leaf | ((uint64_t)node << 8) | ((uint64_t)max_level << 16), g);
+    for (height = 0;; height++) {
+        size_t node_len, src, dst;
+        if (height && bcnt == bb) break;            /* one block left: its bytes are the last chaining value */
+        if (height + 1 == max_level) {              /* last allowed level: one chain over everything that is left */
+            ubi_chain(nw, s, g, m, bcnt, 0, height + 1);
+            break;
+        }
+        node_len = bb << (height ? node : leaf);
+        for (src = dst = 0; src <= bcnt;) {
+            size_t n = bcnt - src;
+            uint8_t blk[64];
+            if (n > node_len) n = node_len;
+            ubi_chain(nw, s, g, m + src, n, (uint64_t)src, height + 1);
+            for (size_t k = 0; k < bb; k++) blk[k] = (uint8_t)(s[k >> 3] >> (8 * (k & 7)));
+            memcpy(m + dst, blk, bb);               /* dst <= src: never overtakes unread input */
+            dst += bb;
+            src += n;
+            if (src >= bcnt) break;                 /* (also ends the len == 0 case after one empty leaf) */
+        }
+        bcnt = dst;
+    }
+    while (produced < out_bytes) {
+        uint64_t o[8];
+        uint8_t cblk[64];
+        unsigned n = out_bytes - produced;
+        memcpy(o, s, sizeof o);
+        memset(cblk, 0, sizeof cblk);
+        for (int b = 0; b < 8; b++) cblk[b] = (uint8_t)(ctr >> (8 * b));
+        ubi_block(nw, o, 8, T1_FIRST | T1_FINAL | T1_TYPE(TYPE_OUT), cblk);
+        if (n > bb) n = (unsigned)bb;
+        for (unsigned k = 0; k < n; k++) out[produced + k] = (uint8_t)(o[k >> 3] >> (8 * (k & 7)));
+        produced += n;
+        ctr++;
+    }
+    free(m);
+    return 0;
 }

@@ -69,3 +69,22 @@ def test_iv_512_is_config_block_ubi(oracle):
     # the ShortMsgKAT Len=0 digest exercises exactly IV -> final(empty) -> output
     g = load_golden("skein_kat_512.json")
     assert z.hex() == g["short"][0]["md"]
+
+
+def test_tree_mode_matches_reference_golden_kat(oracle):
+    """Skein tree hashing against every Skein-256 / Skein-512 tree vector of the reference's
+    KAT_MCT/skein_golden_kat.txt (leaf/node/maxLevel 2/2/2, 1/2/3 and 2/1/255)."""
+    vecs = load_golden("skein_kat_tree.json")["vectors"]
+    assert len(vecs) == 23
+    for v in vecs:
+        got = oracle.skein_tree(v["state_bits"], bytes.fromhex(v["msg"]), v["hash_bits"], v["leaf"], v["node"], v["max_level"])
+        assert got.hex() == v["digest"], v
+
+
+def test_tree_mode_degenerate_cases(oracle):
+    # a message that fits one leaf is still not the sequential hash (tree fields change the configuration block)
+    msg = bytes(range(64))
+    assert oracle.skein_tree(512, msg, 512, 1, 1, 2) != oracle.skein512(msg, 512)
+    assert len(oracle.skein_tree(256, b"", 128, 1, 1, 255)) == 16
+    with pytest.raises(ValueError):
+        oracle.skein_tree(512, msg, 512, 0, 1, 2)
