@@ -16,6 +16,7 @@ ABI_SYMBOLS = [
     "cw_set_block_size", "cw_get_block_size",
     "cw_hash_skein", "cw_hash_skein512", "cw_hash_sha256mb", "cw_compress_lz4", "cw_compress_lzf",
     "cw_decompress_lz4", "cw_decompress_lzf",
+    "cw_hash_tree_blocks", "cw_dev_hash_tree",
     "cw_hash_blocks", "cw_compress_blocks", "cw_hash_and_compress_blocks", "cw_decompress_blocks",
     "cw_dev_hash", "cw_dev_compress", "cw_dev_hash_and_compress", "cw_dev_gen_random", "cw_dev_sum_sizes",
     "cw_dev_decompress", "cw_dev_pack", "cw_profile_enable", "cw_profile_read",
@@ -85,6 +86,8 @@ def lib() -> C.CDLL:
         "cw_decompress_lz4": ([vp, vp, C.c_int, C.c_int], C.c_int),
         "cw_decompress_lzf": ([vp, C.c_uint, vp, C.c_uint], C.c_uint),
         "cw_decompress_blocks": ([C.c_int, vp, sz, u32p, sz, vp, sz, u32p], C.c_int),
+        "cw_hash_tree_blocks": ([C.c_int, vp, sz, sz, C.c_uint, C.c_uint, C.c_uint, vp], C.c_int),
+        "cw_dev_hash_tree": ([C.c_int, vp, sz, sz, sz, C.c_uint, C.c_uint, C.c_uint, vp, vp], C.c_int),
         "cw_hash_blocks": ([C.c_int, vp, sz, sz, vp], C.c_int),
         "cw_compress_blocks": ([C.c_int, vp, sz, sz, vp, sz, u32p], C.c_int),
         "cw_hash_and_compress_blocks": ([C.c_int, C.c_int, vp, sz, sz, vp, vp, sz, u32p], C.c_int),

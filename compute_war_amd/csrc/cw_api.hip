@@ -344,6 +344,23 @@ int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, cons
     return CW_OK;
 }
 
+int cw_dev_hash_tree(int hash_alg, const void *d_src, size_t block_bytes, size_t src_stride, size_t nblocks, unsigned leaf, unsigned node,
+                     unsigned max_level, void *d_digests, void *stream)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    if (nblocks == 0) return CW_OK;
+    if (!d_src || !d_digests) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
+    if ((rc = check_block(block_bytes)) != CW_OK) return rc;
+    if (hash_alg != CW_HASH_SKEIN512 && hash_alg != CW_HASH_SKEIN256_128) return fail(CW_ERR_BAD_ARG, "tree hashing is defined for the Skein algorithms only");
+    hipError_t e = cw::skein_tree_launch(hash_alg == CW_HASH_SKEIN512 ? 8 : 4, (const uint8_t *)d_src, block_bytes,
+                                         src_stride ? src_stride : block_bytes, nblocks, hash_alg == CW_HASH_SKEIN512 ? 512u : 128u, leaf,
+                                         node, max_level, (uint8_t *)d_digests, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(CW_ERR_BAD_ARG, "tree parameters leaf=%u node=%u maxLevel=%u not usable for %zu-byte blocks", leaf, node, max_level, block_bytes);
+    if (e != hipSuccess) return fail(CW_ERR_HIP, "tree hash launch: %s", hipGetErrorString(e));
+    return CW_OK;
+}
+
 int cw_dev_pack(const void *d_slots, size_t slot_stride, const uint32_t *d_sizes, size_t nblocks, void *d_packed, uint64_t *d_offsets,
                 void *stream)
 {
@@ -467,6 +484,31 @@ int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, siz
                 }
             }
         }
+        HIP_TRY(hipStreamSynchronize(c.stream));
+    }
+    return CW_OK;
+}
+
+int cw_hash_tree_blocks(int hash_alg, const void *src, size_t block_bytes, size_t nblocks, unsigned leaf, unsigned node, unsigned max_level,
+                        void *digests)
+{
+    ThreadCtx &c = t_ctx;
+    int rc = c.open();
+    if (rc != CW_OK) return rc;
+    if (nblocks == 0) return CW_OK;
+    if ((!src && block_bytes) || !digests) return fail(CW_ERR_BAD_ARG, "NULL pointer");
+    if ((rc = check_block(block_bytes)) != CW_OK) return rc;
+    const size_t db = cw_digest_bytes(hash_alg);
+    if (db == 0) return fail(CW_ERR_BAD_ARG, "unknown hash algorithm %d", hash_alg);
+    size_t chunk = kMaxChunkBytes / (block_bytes + 64);
+    if (chunk == 0) chunk = 1;
+    if (chunk > nblocks) chunk = nblocks;
+    if ((rc = c.src.reserve(chunk * block_bytes + 16)) != CW_OK || (rc = c.dig.reserve(chunk * db)) != CW_OK) return rc;
+    for (size_t first = 0; first < nblocks; first += chunk) {
+        const size_t n = nblocks - first < chunk ? nblocks - first : chunk;
+        if (block_bytes) HIP_TRY(hipMemcpyAsync(c.src.p, (const uint8_t *)src + first * block_bytes, n * block_bytes, hipMemcpyHostToDevice, c.stream));
+        if ((rc = cw_dev_hash_tree(hash_alg, c.src.p, block_bytes, block_bytes, n, leaf, node, max_level, c.dig.p, c.stream)) != CW_OK) return rc;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)digests + first * db, c.dig.p, n * db, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
     }
     return CW_OK;

@@ -15,7 +15,10 @@ namespace cw {
 struct SkeinIV { uint64_t w[8]; };
 
 // host: chaining value after the configuration block (Skein_*_Init)
-void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv);
+void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv, uint64_t tree_info = 0);
+// tree hashing of every block (one wavefront per block, lane = leaf/node); digest = hash_bits / 8 bytes per block
+hipError_t skein_tree_launch(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks,
+                             unsigned hash_bits, unsigned leaf, unsigned node, unsigned max_level, uint8_t *digests, hipStream_t stream);
 
 // device launches (async on `stream`); src_stride = distance between consecutive blocks in bytes
 // lean: the caller runs codec wavefronts beside the hash kernel and wants its low-register variant

@@ -365,6 +365,120 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tree hashing (semantics of the reference's Skein_TreeHash, skein_test.c:616-680, restated on the
+// CPU in oracle/skein_oracle.c and pinned to the reference's tree KAT vectors).  The digests differ from sequential
+// Skein by construction, so this is an extra entry point, not a drop-in: what it buys is parallelism INSIDE a block --
+// one wavefront per block, lane i hashes leaf i (then node i of the next level, ...), so a single 64 KiB block takes
+// 1/64 of the serial chain and a handful of blocks already fills the chip.
+// Level outputs ping-pong between two LDS buffers; a level is one pass of "lane i: UBI chain over node i".
+// ---------------------------------------------------------------------------------------------------
+template <int NW>
+static __device__ __forceinline__ void load_node_words(uint64_t (&w)[NW], const uint8_t *p, size_t n)
+{
+    // n = bytes available (1..NW*8, or 0): whole 8-byte words are read as such, the rest byte-wise, zero padded
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        uint64_t v = 0;
+        if ((size_t)(8 * i + 8) <= n) __builtin_memcpy(&v, p + 8 * i, 8);
+        else
+            for (int b = 0; b < 8; b++)
+                if ((size_t)(8 * i + b) < n) v |= (uint64_t)p[8 * i + b] << (8 * b);
+        w[i] = v;
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64)
+skein_tree_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t src_stride, size_t nblocks, SkeinIV g,
+                  uint8_t *__restrict__ digests, unsigned digest_bytes, unsigned leaf, unsigned node, unsigned max_level,
+                  unsigned cap_a)
+{
+    constexpr unsigned BB = NW * 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lvl[]; // level buffers: [0, cap_a) and [cap_a, ...)
+    const uint32_t lane = threadIdx.x;
+
+    for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const uint8_t *m = src + blk * src_stride;
+        size_t bcnt = block_bytes;
+        uint64_t S[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) S[i] = 0;
+        __syncthreads(); // the previous block's level buffers are free
+        for (unsigned height = 0;; height++) {
+            if (height && bcnt == BB) { // one block left: its bytes are the last chaining value
+                load_node_words<NW>(S, m, BB);
+                break;
+            }
+            const bool last_level = height + 1 == max_level; // hash whatever is left in one chain
+            const size_t node_len = last_level ? bcnt : (size_t)BB << (height ? node : leaf);
+            const size_t nnodes = bcnt == 0 || last_level ? 1 : (bcnt + node_len - 1) / node_len;
+            uint8_t *out = lvl + ((height & 1) ? cap_a : 0);
+            for (size_t i = lane; i < nnodes; i += 64) {
+                const size_t off = i * node_len, n = bcnt - off < node_len ? bcnt - off : node_len;
+                uint64_t X[NW], w[NW];
+#pragma unroll
+                for (int k = 0; k < NW; k++) X[k] = g.w[k];
+                uint64_t t0 = off, t1 = T1_FIRST | T1_MSG | ((uint64_t)(height + 1) << 48); // tree level: tweak bits 112..118
+                for (size_t pos = 0;;) {
+                    const bool fin = n - pos <= BB;
+                    const size_t take = fin ? n - pos : BB;
+                    load_node_words<NW>(w, m + off + pos, take);
+                    t0 += take;
+                    Ubi<NW>::run(X, w, t0, fin ? t1 | T1_FINAL : t1);
+                    t1 &= ~T1_FIRST;
+                    pos += take;
+                    if (fin) break;
+                }
+                if (last_level) {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) S[k] = X[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) *reinterpret_cast<uint64_t *>(out + i * BB + 8 * k) = X[k];
+                }
+            }
+            if (last_level) break; // (lane 0 holds the chain)
+            __syncthreads();
+            m = out;
+            bcnt = nnodes * BB;
+        }
+        if (lane == 0) { // output transform (skein.c:391-405) on the last chaining value
+            uint64_t w[NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) w[k] = 0;
+            Ubi<NW>::run(S, w, 8, T1_FIRST | T1_FINAL | T1_OUT);
+            uint8_t *o = digests + blk * digest_bytes;
+            for (unsigned k = 0; k < digest_bytes; k++) o[k] = (uint8_t)(S[k >> 3] >> (8 * (k & 7)));
+        }
+    }
+}
+
+hipError_t skein_tree_launch(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, unsigned hash_bits,
+                             unsigned leaf, unsigned node, unsigned max_level, uint8_t *digests, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    if ((nw != 4 && nw != 8) || leaf == 0 || node == 0 || max_level < 2 || leaf > 20 || node > 20 || max_level > 255 ||
+        hash_bits == 0 || hash_bits > (unsigned)nw * 64 || hash_bits % 8)
+        return hipErrorInvalidValue;
+    const size_t bb = (size_t)nw * 8;
+    // level-1 output and level-2 output bound the two LDS buffers (later levels only shrink)
+    const size_t n1 = block_bytes ? (block_bytes + (bb << leaf) - 1) / (bb << leaf) : 1;
+    const size_t n2 = (n1 * bb + (bb << node) - 1) / (bb << node);
+    const size_t cap_a = (n1 * bb + 15) & ~(size_t)15, cap_b = (n2 * bb + 15) & ~(size_t)15;
+    if (cap_a + cap_b > 64 * 1024) return hipErrorInvalidValue; // leaves too small for this block size
+    SkeinIV g;
+    skein_compute_iv(nw, hash_bits, &g, (uint64_t)leaf | ((uint64_t)node << 8) | ((uint64_t)max_level << 16));
+    const size_t grid = nblocks < 256 * 8 ? nblocks : 256 * 8;
+    if (nw == 8)
+        hipLaunchKernelGGL(skein_tree_kernel<8>, dim3((unsigned)grid), dim3(64), cap_a + cap_b, stream, src, block_bytes, src_stride,
+                           nblocks, g, digests, hash_bits / 8, leaf, node, max_level, (unsigned)cap_a);
+    else
+        hipLaunchKernelGGL(skein_tree_kernel<4>, dim3((unsigned)grid), dim3(64), cap_a + cap_b, stream, src, block_bytes, src_stride,
+                           nblocks, g, digests, hash_bits / 8, leaf, node, max_level, (unsigned)cap_a);
+    return hipGetLastError();
+}
+
 template <int NW>
 static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
                                uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean)
@@ -410,7 +524,7 @@ hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_st
 // ---- host-side config-block UBI (Skein_*_Init's "no precomputed IV" path, skein.c:245-259) ----
 static uint64_t h_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
-void skein_compute_iv(int nw, unsigned hash_bits, SkeinIV *iv)
+void skein_compute_iv(int nw, unsigned hash_bits, SkeinIV *iv, uint64_t tree_info)
 {
     static const int rot8[8][4] = {{38, 30, 50, 53}, {48, 20, 43, 31}, {34, 14, 15, 27}, {26, 12, 58, 7},
                                    {33, 49, 8, 42},  {39, 27, 41, 14}, {29, 26, 11, 9},  {33, 51, 39, 35}};
@@ -418,7 +532,8 @@ void skein_compute_iv(int nw, unsigned hash_bits, SkeinIV *iv)
     static const int perm8[8] = {2, 1, 4, 7, 6, 5, 0, 3}, perm4[4] = {0, 3, 2, 1};
     uint64_t ks[9] = {0}, ts[3], w[8] = {0}, v[8], t[8];
     w[0] = (1ULL << 32) | 0x33414853ULL; // schema version 1, "SHA3"
-    w[1] = hash_bits;                    // w[2] = 0: sequential (no tree)
+    w[1] = hash_bits;
+    w[2] = tree_info;                    // 0 = sequential; leaf | node << 8 | maxLevel << 16 (skein.h:209-210)
     ks[nw] = KS_PARITY;                  // chaining value is all zero
     ts[0] = 32;                          // config string length
     ts[1] = T1_FIRST | T1_FINAL | (4ULL << 56);

@@ -90,6 +90,22 @@ def hash_blocks(alg, src, block_bytes: int) -> np.ndarray:
     return out
 
 
+def hash_tree_blocks(alg, src, block_bytes: int, leaf: int, node: int, max_level: int):
+    """Skein tree digests of every block of `src` (cw_hash_tree_blocks): [n, digest_bytes] uint8."""
+    a = _np_u8(src)
+    n = a.size // block_bytes if block_bytes else 0
+    hid = _hash_id(alg)
+    digests = np.zeros((n, digest_bytes(hid)), dtype=np.uint8)
+    check(lib().cw_hash_tree_blocks(hid, a.ctypes.data, block_bytes, n, leaf, node, max_level, digests.ctypes.data))
+    return digests
+
+
+def dev_hash_tree(alg, d_src: int, block_bytes: int, nblocks: int, leaf: int, node: int, max_level: int, d_digests: int,
+                  stream: int = 0, src_stride: int = 0) -> None:
+    check(lib().cw_dev_hash_tree(_hash_id(alg), d_src, block_bytes, src_stride or block_bytes, nblocks, leaf, node, max_level,
+                                 d_digests, stream))
+
+
 def compress_blocks(alg, src, block_bytes: int):
     """Returns (sizes[n] uint32, payload[n, stride] uint8)."""
     a = _np_u8(src)

@@ -105,6 +105,9 @@ int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, siz
                                 uint32_t *sizes);
 /* decode nblocks slots (comp_stride apart, sizes[i] bytes each) into nblocks * block_bytes at dst;
  * status[i] = 0 iff slot i is well formed and yields exactly block_bytes (see cw_dev_decompress).  */
+/* host-buffer form of cw_dev_hash_tree */
+int cw_hash_tree_blocks(int hash_alg, const void *src, size_t block_bytes, size_t nblocks, unsigned leaf, unsigned node,
+                        unsigned max_level, void *digests);
 int cw_decompress_blocks(int comp_alg, const void *comp, size_t comp_stride, const uint32_t *sizes,
                          size_t nblocks, void *dst, size_t block_bytes, uint32_t *status);
 
@@ -124,6 +127,14 @@ int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size
  * block_bytes.  Used as the reference-independent round-trip verifier of the compressors.                     */
 int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, const uint32_t *d_sizes, size_t nblocks,
                       void *d_dst, size_t block_bytes, uint32_t *d_status, void *stream);
+/* Skein tree hashing of every block (the reference's Skein_TreeHash,
+ * reference_code/skein/Additional_Implementations/skein_test.c:616-680, tree fields skein.h:209-210): leaves of
+ * state_bytes << leaf bytes, nodes of state_bytes << node bytes, at most max_level levels (>= 2; 255 = unlimited).
+ * NOT the digest of cw_dev_hash -- tree mode changes the configuration block -- but one wavefront hashes a block with
+ * lane-per-leaf parallelism, so a few large blocks already fill the GPU.  hash_alg: CW_HASH_SKEIN512 (64-byte digests)
+ * or CW_HASH_SKEIN256_128 (16-byte digests).  The level buffers live in LDS: (block_bytes >> leaf) * 1.5 <= 64 KiB.   */
+int cw_dev_hash_tree(int hash_alg, const void *d_src, size_t block_bytes, size_t src_stride, size_t nblocks,
+                     unsigned leaf, unsigned node, unsigned max_level, void *d_digests, void *stream);
 /* Packed output stream + block index: d_offsets[i] = sum of d_sizes[0..i) (u64, nblocks + 1
  * entries, the last one is the total); slot i's d_sizes[i] bytes are copied to d_packed + d_offsets[i].  A block that
  * did not fit (size 0) occupies nothing.  d_packed may be NULL: index only.  d_packed needs sum(d_sizes) bytes

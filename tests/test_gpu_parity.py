@@ -462,3 +462,29 @@ def test_lane_order_fallback_path_is_exact():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] and len(outs[0].splitlines()) == 4
+
+
+@pytest.mark.parametrize("alg,state_bits,hash_bits", [("skein512", 512, 512), ("skein", 256, 128)])
+def test_tree_hash_matches_oracle(cw, oracle, alg, state_bits, hash_bits):
+    """N4: Skein tree hashing, one wavefront per block with a lane per leaf, against the oracle (which is pinned to the
+    reference's tree KAT vectors): the KAT parameter sets and storage-block shapes, ragged and empty included."""
+    rng = np.random.default_rng(state_bits)
+    for bs, count, params in [(65536, 9, [(4, 3, 255), (2, 2, 255), (4, 3, 2), (6, 1, 3)]),
+                              (4096, 70, [(2, 2, 2), (1, 2, 3), (2, 1, 255), (3, 3, 255)]),
+                              (1019, 33, [(2, 2, 2), (1, 2, 3), (2, 1, 255)]),
+                              (64, 5, [(1, 1, 255)]), (31, 3, [(1, 2, 3)])]:
+        data = rng.integers(0, 256, bs * count, dtype=np.uint8).tobytes()
+        for leaf, node, ml in params:
+            dig = cw.hash_tree_blocks(alg, data, bs, leaf, node, ml)
+            for i in range(count):
+                want = oracle.skein_tree(state_bits, data[i * bs:(i + 1) * bs], hash_bits, leaf, node, ml)
+                assert dig[i].tobytes() == want, (alg, bs, i, leaf, node, ml)
+    # the reference's own vectors with 512-bit results through the device path
+    for v in load_golden("skein_kat_tree.json")["vectors"]:
+        if (v["state_bits"], v["hash_bits"]) == (state_bits, hash_bits):
+            msg = bytes.fromhex(v["msg"])
+            assert cw.hash_tree_blocks(alg, msg, len(msg), v["leaf"], v["node"], v["max_level"])[0].tobytes().hex() == v["digest"]
+    with pytest.raises(cw.CwError):
+        cw.hash_tree_blocks("sha256mb", data, 31, 1, 1, 2)
+    with pytest.raises(cw.CwError):
+        cw.hash_tree_blocks(alg, bytes(65536), 65536, 0, 1, 2)
