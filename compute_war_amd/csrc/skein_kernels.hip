@@ -469,7 +469,7 @@ hipError_t skein_tree_launch(int nw, const uint8_t *src, size_t block_bytes, siz
     if (cap_a + cap_b > 64 * 1024) return hipErrorInvalidValue; // leaves too small for this block size
     SkeinIV g;
     skein_compute_iv(nw, hash_bits, &g, (uint64_t)leaf | ((uint64_t)node << 8) | ((uint64_t)max_level << 16));
-    const size_t grid = nblocks < 256 * 8 ? nblocks : 256 * 8;
+    const size_t grid = nblocks < 256 * 16 ? nblocks : 256 * 16; // 4 wavefronts per SIMD (VGPR bound)
     if (nw == 8)
         hipLaunchKernelGGL(skein_tree_kernel<8>, dim3((unsigned)grid), dim3(64), cap_a + cap_b, stream, src, block_bytes, src_stride,
                            nblocks, g, digests, hash_bits / 8, leaf, node, max_level, (unsigned)cap_a);

@@ -17,6 +17,7 @@ ap.add_argument("--comp", default="")
 ap.add_argument("--bs", type=int, default=65536)
 ap.add_argument("--nb", type=int, default=262144)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--tree", default="", help="leaf,node,maxlevel: Skein tree hashing instead of sequential")
 ap.add_argument("--data", default="random", choices=["random", "zero", "text"])
 a = ap.parse_args()
 
@@ -43,6 +44,9 @@ def run():
         cw.dev_hash_and_compress(a.alg, a.comp, src.data_ptr(), a.bs, a.nb, dig.data_ptr(), dst.data_ptr(), stride, sizes.data_ptr(), s)
     elif a.comp:
         cw.dev_compress(a.comp, src.data_ptr(), a.bs, a.nb, dst.data_ptr(), stride, sizes.data_ptr(), s)
+    elif a.tree:
+        leaf, node, ml = (int(x) for x in a.tree.split(","))
+        cw.dev_hash_tree(a.alg, src.data_ptr(), a.bs, a.nb, leaf, node, ml, dig.data_ptr(), s)
     else:
         cw.dev_hash(a.alg, src.data_ptr(), a.bs, a.nb, dig.data_ptr(), s)
 
