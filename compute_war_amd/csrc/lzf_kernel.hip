@@ -415,7 +415,7 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 {
     // LDS: the 128 KiB table, then the block (coalesced copy; positions are then read as aligned dwords)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *stage = smem + kLzfTabBytes;
+    uint8_t *stage = smem + kLzfTabBytes; // kChainMax + 48 bytes
     const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(smem);
     const uint32_t lane = threadIdx.x;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0 && n <= 8192;
@@ -442,60 +442,70 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
         __syncthreads();
 #pragma unroll 16
         for (uint32_t i = 0; i < kLzfTabBytes / 16 / 64; i++) reinterpret_cast<uint4 *>(smem)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        if (vec) {
-            CW_STAGE1(0) CW_STAGE1(1) CW_STAGE1(2) CW_STAGE1(3) CW_STAGE1(4) CW_STAGE1(5) CW_STAGE1(6) CW_STAGE1(7)
-            CW_PREFETCH(blk + gridDim.x);
-        } else {
-            for (uint32_t i = lane; i < n; i += 64) stage[i] = g[i];
-        }
-        if (lane < 16) stage[((n + 15u) & ~15u) + lane] = 0; // slack read by the dword loads
-        __syncthreads();
-
         bool bad = force_redo != 0;
-        // the dwords around the positions of a round are read one round ahead, so that a round has ONE LDS wait
-        uint32_t lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t pos = 64 * k + lane;
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + ((pos + 2 < n ? pos : 0u) >> 2);
-            lo[k] = w[0]; hi[k] = w[1];
-        }
-        for (uint32_t base = 0; base + 2 < n && !bad; base += 256) {
-            uint32_t addr[4], mask[4], data[4], old[4], sh[4];
-            bool ok[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t pos = base + 64 * k + lane;
-                ok[k] = pos + 2 < n;
-                const uint32_t v = __builtin_amdgcn_alignbyte(hi[k], lo[k], (ok[k] ? pos : 0u) & 3u);
-                const uint32_t slot = lzf_slot(v & 0xFFu, (v >> 8) & 0xFFu, (v >> 16) & 0xFFu);
-                sh[k] = (slot & 1u) * 16;
-                addr[k] = tab_lds + (slot >> 1) * 4;
-                mask[k] = ok[k] ? 0xFFFFu << sh[k] : 0u; // a lane without a position exchanges nothing
-                data[k] = ok[k] ? pos << sh[k] : 0u;
+        // the block passes through the staging area in pieces of kChainMax bytes (one piece for small blocks)
+        for (uint32_t p0 = 0; p0 < n && !bad; p0 += kChainMax) {
+            const uint32_t pn = n - p0 < kChainMax + 16 ? n - p0 : kChainMax + 16; // + the bytes the last positions hash
+            if (p0) __syncthreads();
+            if (vec) {
+                CW_STAGE1(0) CW_STAGE1(1) CW_STAGE1(2) CW_STAGE1(3) CW_STAGE1(4) CW_STAGE1(5) CW_STAGE1(6) CW_STAGE1(7)
+                CW_PREFETCH(blk + gridDim.x);
+            } else if (((reinterpret_cast<uintptr_t>(g) | p0) & 15) == 0) {
+                for (uint32_t i = lane; i < (pn + 15) / 16; i += 64)
+                    if (i * 16 + 16 <= pn) reinterpret_cast<uint4 *>(stage)[i] = reinterpret_cast<const uint4 *>(g + p0)[i];
+                    else for (uint32_t b = i * 16; b < pn; b++) stage[b] = g[p0 + b];
+            } else {
+                for (uint32_t i = lane; i < pn; i += 64) stage[i] = g[p0 + i];
             }
+            if (lane < 16) stage[((pn + 15u) & ~15u) + lane] = 0; // slack read by the dword loads
+            __syncthreads();
+
+            const uint32_t pend = p0 + kChainMax < n ? p0 + kChainMax : n; // positions [p0, pend) belong to this piece
+            // the dwords around the positions of a round are read one round ahead, so that a round has ONE LDS wait
+            uint32_t lo[4], hi[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t pos = base + 256 + 64 * k + lane;
-                const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + ((pos + 2 < n ? pos : 0u) >> 2);
+                const uint32_t pos = p0 + 64 * k + lane;
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + ((pos + 2 < n && pos < pend ? pos - p0 : 0u) >> 2);
                 lo[k] = w[0]; hi[k] = w[1];
             }
-            // four exchanges back to back: the LDS runs them in order, lanes ascending inside each
-            asm volatile("ds_mskor_rtn_b32 %0, %4, %8, %12\n\t"
-                         "ds_mskor_rtn_b32 %1, %5, %9, %13\n\t"
-                         "ds_mskor_rtn_b32 %2, %6, %10, %14\n\t"
-                         "ds_mskor_rtn_b32 %3, %7, %11, %15\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
-                         : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]),
-                           "v"(data[0]), "v"(data[1]), "v"(data[2]), "v"(data[3])
-                         : "memory");
+            for (uint32_t base = p0; base < pend && base + 2 < n && !bad; base += 256) {
+                uint32_t addr[4], mask[4], data[4], old[4], sh[4];
+                bool ok[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t pos = base + 64 * k + lane;
-                const uint32_t o = ok[k] ? (old[k] >> sh[k]) & 0xFFFFu : 0u;
-                if (__ballot(ok[k] && o >= pos && (o | pos) != 0)) bad = true; // not in lane order
-                if (pos < n2) out[pos] = (uint16_t)o;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t pos = base + 64 * k + lane;
+                    ok[k] = pos + 2 < n && pos < pend;
+                    const uint32_t v = __builtin_amdgcn_alignbyte(hi[k], lo[k], (ok[k] ? pos - p0 : 0u) & 3u);
+                    const uint32_t slot = lzf_slot(v & 0xFFu, (v >> 8) & 0xFFu, (v >> 16) & 0xFFu);
+                    sh[k] = (slot & 1u) * 16;
+                    addr[k] = tab_lds + (slot >> 1) * 4;
+                    mask[k] = ok[k] ? 0xFFFFu << sh[k] : 0u; // a lane without a position exchanges nothing
+                    data[k] = ok[k] ? pos << sh[k] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t pos = base + 256 + 64 * k + lane;
+                    const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + ((pos + 2 < n && pos < pend ? pos - p0 : 0u) >> 2);
+                    lo[k] = w[0]; hi[k] = w[1];
+                }
+                // four exchanges back to back: the LDS runs them in order, lanes ascending inside each
+                asm volatile("ds_mskor_rtn_b32 %0, %4, %8, %12\n\t"
+                             "ds_mskor_rtn_b32 %1, %5, %9, %13\n\t"
+                             "ds_mskor_rtn_b32 %2, %6, %10, %14\n\t"
+                             "ds_mskor_rtn_b32 %3, %7, %11, %15\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                             : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]),
+                               "v"(data[0]), "v"(data[1]), "v"(data[2]), "v"(data[3])
+                             : "memory");
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t pos = base + 64 * k + lane;
+                    const uint32_t o = ok[k] ? (old[k] >> sh[k]) & 0xFFFFu : 0u;
+                    if (__ballot(ok[k] && o >= pos && (o | pos) != 0)) bad = true; // not in lane order
+                    if (pos < pend || (pend == n && pos < n2)) out[pos] = (uint16_t)o;
+                }
             }
         }
         if (lane == 0) sizes[blk] = bad ? kRedo : 0u; // 0 = "links are valid" for lzf_chain_kernel
@@ -505,14 +515,19 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 #undef CW_STAGE1
 }
 
+// BIG = false: links + flags and the block in LDS (blocks <= 16 KiB).  BIG = true: the links stay in global memory, the
+// block is read from global memory, only the skip flags (one bit per position) are in LDS -- 8 KiB for a 64 KiB block,
+// so 16 blocks fit a CU where the table-based kernel fits one; a chain step then costs a global round trip.
+template <bool BIG>
 __global__ void __launch_bounds__(64)
 lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst,
                  size_t dst_stride, uint32_t *__restrict__ sizes, const uint16_t *__restrict__ links, uint32_t n2,
                  uint32_t *__restrict__ counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t *E = reinterpret_cast<uint16_t *>(smem);          // link | kSkipFlag, n2 entries
-    uint8_t *stage = smem + 2 * (size_t)n2;                     // the block, + 16 bytes of slack
+    uint16_t *E = reinterpret_cast<uint16_t *>(smem);          // !BIG: link | kSkipFlag, n2 entries
+    uint8_t *stage = smem + 2 * (size_t)n2;                     // !BIG: the block, + 16 bytes of slack
+    uint32_t *skipmap = reinterpret_cast<uint32_t *>(smem);     // BIG: one bit per position
     __shared__ uint32_t mailbox;
     const uint32_t lane = threadIdx.x;
     const uint32_t cap = n - 1;
@@ -522,25 +537,31 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
         __syncthreads();
         if (lane == 0) mailbox = atomicAdd(counter, 1u);
         __syncthreads();
-        const size_t blk = mailbox;
+        const size_t blk = __builtin_amdgcn_readfirstlane(mailbox);
         if (blk >= nblocks) break;
         if (__builtin_amdgcn_readfirstlane(sizes[blk]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
-        {
-            const uint4 *l4 = reinterpret_cast<const uint4 *>(links + blk * (size_t)n2);
+        const uint16_t *lk = links + blk * (size_t)n2;
+        if (BIG) {
+            for (uint32_t i = lane; i < n2 / 32; i += 64) skipmap[i] = 0;
+        } else {
+            const uint4 *l4 = reinterpret_cast<const uint4 *>(lk);
             for (uint32_t i = lane; i < n2 / 8; i += 64) reinterpret_cast<uint4 *>(E)[i] = l4[i];
             for (uint32_t i = lane; i < n; i += 64) stage[i] = g[i];
             if (lane < 16) stage[n + lane] = 0;
         }
         __syncthreads();
-        const uint8_t *in = stage;
+        const uint8_t *in = BIG ? g : stage;
 
         uint32_t ip = 0, op = 1, lit = 0;
         bool fail = (n == 0 || cap == 0);
         auto request = [&](uint32_t ip_) __attribute__((always_inline)) -> uint32_t {
             const uint32_t pos = ip_ + lane;
-            return lz::rd32x<true>(in, pos + 2 < n ? pos : 0u);
+            if (!BIG) return lz::rd32x<true>(in, pos + 2 < n ? pos : 0u);
+            const uint32_t p = pos + 2 < n ? pos : 0u;
+            const uint32_t q = p + 4 <= n ? p : p - 1; // pos = n - 3: read one byte earlier and shift (no read past the block)
+            return lz::rd32(in, q) >> ((p - q) * 8);
         };
         uint32_t vnext = fail ? 0u : request(0);
         uint32_t head = kChainHead;
@@ -551,20 +572,35 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             const uint32_t ntest = (uint32_t)__builtin_popcountll(__ballot(tested));
             const uint32_t v = vnext;
             // the reference the serial parser would read: first position on the link chain that was inserted
-            uint32_t cur = tested ? E[pos] & 0x7FFFu : 0u;
-            for (;;) {
-                const uint32_t e = cur ? E[cur] : 0u;
-                const bool skipped = (e & kSkipFlag) != 0;
-                if (skipped) cur = e & 0x7FFFu;
-                if (!__ballot(skipped)) break;
+            uint32_t cur;
+            if (BIG) {
+                cur = tested ? lk[pos] : 0u;
+                for (;;) {
+                    const bool skipped = cur && ((skipmap[cur >> 5] >> (cur & 31u)) & 1u);
+                    if (skipped) cur = lk[cur];
+                    if (!__ballot(skipped)) break;
+                }
+            } else {
+                cur = tested ? E[pos] & 0x7FFFu : 0u;
+                for (;;) {
+                    const uint32_t e = cur ? E[cur] : 0u;
+                    const bool skipped = (e & kSkipFlag) != 0;
+                    if (skipped) cur = e & 0x7FFFu;
+                    if (!__ballot(skipped)) break;
+                }
             }
             const uint32_t old = cur;
             const bool cand = tested && old > 0 && pos - old - 1 < kMaxOff;
             lz::Around ap, ac;
             ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 1u << 24; ac.after = 1;
+            const bool wide = !BIG || pos + 12 <= n; // all 16 bytes readable (reference < position)
             if (cand) {
-                ac = lz::around<true>(in, old, false);
-                ap = lz::around<true>(in, pos, false);
+                if (wide) {
+                    ac = lz::around<!BIG>(in, old, false);
+                    ap = lz::around<!BIG>(in, pos, false);
+                } else {
+                    ac.at = in[old] | (in[old + 1] << 8) | (in[old + 2] << 16) | (~v & 0xFF000000u); // 4th byte: "differs"
+                }
             }
             const unsigned long long mm = __ballot(cand && ((ac.at ^ v) & 0xFFFFFFu) == 0);
             const uint32_t w = mm ? (uint32_t)__builtin_ctzll(mm) : 64u;
@@ -574,10 +610,12 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             bool more_eq = false;
             if (mm) {
                 const uint64_t x = ap.after ^ ac.after;
-                const uint32_t e = (ac.at ^ v) >> 24 ? 0u : 1u + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u);
-                const uint32_t packed = __builtin_amdgcn_readlane(e | (old << 8), w);
-                eqs = packed & 0xFFu; ref = packed >> 8;
-                more_eq = eqs == 9;
+                uint32_t e = (ac.at ^ v) >> 24 ? 0u : 1u + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u);
+                bool me = e == 9;
+                if (!wide) { e = 0; me = true; } // nothing was compared beyond the 3 bytes
+                const uint32_t packed = __builtin_amdgcn_readlane(e | ((uint32_t)me << 4), w);
+                eqs = packed & 0xFu; more_eq = (packed >> 4) & 1u;
+                ref = __builtin_amdgcn_readlane(old, w);
             }
             if (nlit) {
                 const uint32_t last = op + (nlit - 1) + (lit + nlit - 1) / kMaxLit;
@@ -630,7 +668,8 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             // the inside of the match is never inserted (VERY_FAST re-inserts only its last two positions)
             for (uint32_t i = lane; i + 3 < len; i += 64) {
                 const uint32_t q = ip + 1 + i;
-                atomicOr(reinterpret_cast<uint32_t *>(E) + (q >> 1), kSkipFlag << ((q & 1u) * 16));
+                if (BIG) atomicOr(&skipmap[q >> 5], 1u << (q & 31u));
+                else atomicOr(reinterpret_cast<uint32_t *>(E) + (q >> 1), kSkipFlag << ((q & 1u) * 16));
             }
             ip += len;
             const bool go_on = ip + 2 < n;
@@ -702,10 +741,12 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const bool cut_only = mode && strcmp(mode, "cut") == 0, table_only = mode && strcmp(mode, "table") == 0;
     static const char *redo_env = getenv("CW_LZ_FORCE_REDO"); // test knob, see lz4_kernel.hip
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
-    if (!cut_only && !table_only && n <= kChainMax && n >= 16) {
-        // small blocks: links for a chunk of blocks, then the chain parser over that chunk
+    if (!cut_only && !table_only && n >= 16) {
+        // links for a round of blocks, then the chain parser over that round
+        const bool big = n > kChainMax;
         const uint32_t n2 = (n + 63u) & ~63u;
-        const size_t chunk_max = ((size_t)256 << 20) / (2 * (size_t)n2); // 256 MiB of links per round
+        const size_t ws_bytes = big ? (size_t)1 << 30 : (size_t)256 << 20; // links per round
+        const size_t chunk_max = ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
         LinkSpace ls;
         {
@@ -727,25 +768,30 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         static bool chain_attr = false;
         if (!chain_attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_links_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kChainMax + 32);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_chain_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kChainMax + 48);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_chain_kernel<false>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kChainMax + 256);
             if (e != hipSuccess) return e;
             chain_attr = true;
         }
-        const uint32_t chain_lds = 2 * n2 + ((n + 15u) & ~15u) + 16u;
+        const uint32_t links_lds = kLzfTabBytes + ((big ? kChainMax + 16 : n) + 15u) / 16u * 16u + 32u;
+        const uint32_t chain_lds = big ? n2 / 8 + 16u : 2 * n2 + ((n + 15u) & ~15u) + 16u;
         size_t per_cu = (160u * 1024u) / (chain_lds + 64);
-        if (per_cu > 16) per_cu = 16;
+        if (per_cu > (big ? 20u : 16u)) per_cu = big ? 20 : 16;
         for (size_t first = 0; first < nblocks; first += chunk) {
             const size_t nb = nblocks - first < chunk ? nblocks - first : chunk;
             const uint8_t *s0 = src + first * src_stride;
             hipError_t e = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), kLzfTabBytes + ((n + 15u) & ~15u) + 16u, stream, s0, n, src_stride,
+            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, s0, n, src_stride,
                                nb, ls.p, n2, sizes + first, force_redo);
             const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
-            hipLaunchKernelGGL(lzf_chain_kernel, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
-                               dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter);
+            if (big)
+                hipLaunchKernelGGL(lzf_chain_kernel<true>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
+                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter);
+            else
+                hipLaunchKernelGGL(lzf_chain_kernel<false>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
+                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
