@@ -743,7 +743,10 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
     if (!cut_only && !table_only && n >= 16) {
         // links for a round of blocks, then the chain parser over that round
-        const bool big = n > kChainMax;
+        static const char *lm_env = getenv("CW_LZF_LDS_MAX"); // profiling knob: largest block parsed from LDS-resident links
+        // measured (text): 4 KiB 13.2 (LDS) vs 12.4 GB/s (global links); 8 KiB 7.2 vs 10.6; 16 KiB 3.7 vs 9.3 -- blocks per CU win
+        const uint32_t lds_max = lm_env && atoi(lm_env) > 0 ? (uint32_t)atoi(lm_env) : 4096u;
+        const bool big = n > (lds_max < kChainMax ? lds_max : kChainMax);
         const uint32_t n2 = (n + 63u) & ~63u;
         const size_t ws_bytes = big ? (size_t)1 << 30 : (size_t)256 << 20; // links per round
         const size_t chunk_max = ws_bytes / (2 * (size_t)n2);
