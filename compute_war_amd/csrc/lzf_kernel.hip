@@ -563,7 +563,12 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             const uint32_t q = p + 4 <= n ? p : p - 1; // pos = n - 3: read one byte earlier and shift (no read past the block)
             return lz::rd32(in, q) >> ((p - q) * 8);
         };
-        uint32_t vnext = fail ? 0u : request(0);
+        // BIG: the link of every position of the next batch is requested together with its bytes (one round trip less)
+        auto request_link = [&](uint32_t ip_) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t pos = ip_ + lane;
+            return BIG ? (uint32_t)lk[pos + 2 < n ? pos : 0u] : 0u;
+        };
+        uint32_t vnext = fail ? 0u : request(0), lnext = fail ? 0u : request_link(0);
         uint32_t head = kChainHead;
 
         while (!fail && ip + 2 < n) {
@@ -574,7 +579,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             // the reference the serial parser would read: first position on the link chain that was inserted
             uint32_t cur;
             if (BIG) {
-                cur = tested ? lk[pos] : 0u;
+                cur = tested ? lnext : 0u;
                 for (;;) {
                     const bool skipped = cur && ((skipmap[cur >> 5] >> (cur & 31u)) & 1u);
                     if (skipped) cur = lk[cur];
@@ -630,7 +635,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 ip += nlit;
             }
             if (!mm) {
-                if (ip + 2 < n) vnext = request(ip);
+                if (ip + 2 < n) { vnext = request(ip); lnext = request_link(ip); }
                 head = head < 64 ? head * 2 : 64;
                 continue;
             }
@@ -673,7 +678,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             }
             ip += len;
             const bool go_on = ip + 2 < n;
-            if (go_on) vnext = request(ip);
+            if (go_on) { vnext = request(ip); lnext = request_link(ip); }
             if (lane == 0) {
                 if (l2 < 7) {
                     out[at] = (uint8_t)((off >> 8) + (l2 << 5));
