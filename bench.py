@@ -67,8 +67,6 @@ def host_cpu_share() -> int:
 
 def cpu_baseline(args, target_s: float):
     """Oracle (CPU restatement of the reference's worker loop) on a bounded sample of the same workload."""
-    import numpy as np
-
     import oracle as O
     O.build()
     threads = host_cpu_share()

@@ -8,8 +8,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import (anchor_input, corpus_file, corpus_large_file, corpus_large_names, corpus_names, load_golden,
-                      seeded_block)
+from conftest import anchor_input, corpus_file, corpus_large_file, corpus_large_names, corpus_names, load_golden
 
 
 def test_survey_anchor_sizes_and_digests(oracle):

@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
 """Quick device-side throughput probe of one hash / codec kernel (not the contract bench)."""
 import argparse
-import ctypes as C
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
