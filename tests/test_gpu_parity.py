@@ -488,3 +488,24 @@ def test_tree_hash_matches_oracle(cw, oracle, alg, state_bits, hash_bits):
         cw.hash_tree_blocks("sha256mb", data, 31, 1, 1, 2)
     with pytest.raises(cw.CwError):
         cw.hash_tree_blocks(alg, bytes(65536), 65536, 0, 1, 2)
+
+
+def test_lz4_span_scan_with_strides_on_incompressible_blocks(cw, oracle):
+    """The span scan kernel (power-of-two sizes, 64 KiB spans) writes the literal run itself: incompressible blocks with
+    src_stride > block size, a dst_stride that is not a multiple of 16, whole spans plus a tail that does not fill one."""
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(99)
+    for bs, nb, sstride in ((4096, 50, 4096 + 32), (16384, 9, 16384 + 16), (65536, 3, 65536), (8192, 17, 8192 + 4096)):
+        raw = rng.integers(0, 256, sstride * nb, dtype=np.uint8)
+        raw[3 * sstride: 3 * sstride + bs // 2] = 7                      # one compressible block among them
+        dev = torch.from_numpy(raw).cuda()
+        dstride = cw.compress_bound("lz4", bs) + 5
+        dst = torch.zeros(nb * dstride + 64, dtype=torch.uint8, device="cuda")
+        sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        cw.dev_compress("lz4", dev.data_ptr(), bs, nb, dst.data_ptr(), dstride, sizes.data_ptr(), s, src_stride=sstride)
+        torch.cuda.synchronize()
+        hz, hdst = sizes.cpu().numpy(), dst.cpu().numpy()
+        for i in range(nb):
+            want = oracle.lz4_compress(raw[i * sstride: i * sstride + bs].tobytes())
+            assert hz[i] == len(want) and hdst[i * dstride: i * dstride + len(want)].tobytes() == want, (bs, i)
