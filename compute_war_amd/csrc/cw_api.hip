@@ -168,10 +168,21 @@ int check_block(size_t block_bytes)
     return CW_OK;
 }
 
-int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, uint8_t *d_dig, hipStream_t s, bool lean = false)
+// sliced: the caller runs codec wavefronts beside the hash; long Skein messages are then hashed in several launches
+int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, uint8_t *d_dig, hipStream_t s, bool lean = false,
+             bool sliced = false)
 {
     hipError_t e;
     ProfScope prof(PROF_HASH, s);
+    static const char *slice_env = getenv("CW_SKEIN_SLICED"); // CW_SKEIN_SLICED=0: whole-block hash kernel also in the fused call
+    if (sliced && !(slice_env && slice_env[0] == '0') && (alg == CW_HASH_SKEIN512 || alg == CW_HASH_SKEIN256_128)) {
+        const int nw = alg == CW_HASH_SKEIN512 ? 8 : 4;
+        if (cw::skein_sliced_applies(nw, d_src, bb, stride, n)) {
+            e = cw::skein_sliced_launch(nw, d_src, bb, stride, n, nw == 8 ? g_iv512_512 : g_iv256_128, d_dig, nw == 8 ? 64 : 16, s);
+            if (e != hipSuccess) return fail(CW_ERR_HIP, "hash launch: %s", hipGetErrorString(e));
+            return CW_OK;
+        }
+    }
     switch (alg) {
     case CW_HASH_SKEIN512: e = cw::skein512_launch(d_src, bb, stride, n, g_iv512_512, d_dig, 64, s, lean); break;
     case CW_HASH_SKEIN256_128: e = cw::skein256_launch(d_src, bb, stride, n, g_iv256_128, d_dig, 16, s, lean); break;
@@ -242,6 +253,7 @@ void cw_shutdown(void)
     std::lock_guard<std::mutex> g(g_lock);
     if (g_device.load() < 0) return;
     (void)hipDeviceSynchronize();
+    cw::skein_release_workspaces();
     cw::lz4_release_workspaces();
     cw::lzf_release_workspaces();
     cw::pack_release_workspaces();
@@ -322,7 +334,8 @@ int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size
     rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
     if (rc == CW_OK) {
         if (!d_digests) rc = fail(CW_ERR_BAD_ARG, "NULL device pointer");
-        else rc = dev_hash(hash_alg, (const uint8_t *)d_src, block_bytes, src_stride, nblocks, (uint8_t *)d_digests, t_side.side);
+        else rc = dev_hash(hash_alg, (const uint8_t *)d_src, block_bytes, src_stride ? src_stride : block_bytes, nblocks, (uint8_t *)d_digests,
+                           t_side.side, false, true);
     }
     HIP_TRY(hipEventRecord(t_side.join, t_side.side));
     HIP_TRY(hipStreamWaitEvent(main_s, t_side.join, 0));

@@ -16,6 +16,10 @@ struct SkeinIV { uint64_t w[8]; };
 
 // host: chaining value after the configuration block (Skein_*_Init)
 void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv, uint64_t tree_info = 0);
+// sliced Skein for the fused call: the steps of every block in 8 launches (see skein_kernels.hip)
+bool skein_sliced_applies(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks);
+hipError_t skein_sliced_launch(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
+                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
 // tree hashing of every block (one wavefront per block, lane = leaf/node); digest = hash_bits / 8 bytes per block
 hipError_t skein_tree_launch(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks,
                              unsigned hash_bits, unsigned leaf, unsigned node, unsigned max_level, uint8_t *digests, hipStream_t stream);
@@ -38,6 +42,7 @@ hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, c
 hipError_t pack_launch(const uint8_t *slots, size_t slot_stride, const uint32_t *sizes, size_t nblocks, uint8_t *packed,
                        uint64_t *offsets, hipStream_t stream);
 // per-stream scratch of the codec / pack launches (queues, link arrays, scan partials): freed by cw_shutdown
+void skein_release_workspaces();
 void lz4_release_workspaces();
 void lzf_release_workspaces();
 void pack_release_workspaces();

@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "cw_device.h"
 
 namespace cw {
@@ -363,6 +366,154 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     } else {
         for (unsigned k = 0; k < digest_bytes; k++) out[k] = (uint8_t)(X[k >> 3] >> (8 * (k & 7)));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sliced launches for the fused call: the steps of a block are cut into kSkeinSlices launches of short-lived wavefronts
+// that hand the chaining values on through a state array (kernel boundaries order and publish it: no flags, no
+// spinning -- a persistent-grid version with in-kernel dependencies lost to the oldest-first issue order).
+// Beside the codec this is 61.6 instead of 64.5 ms per Mi blocks of 64 KiB: the scan then finishes after 33 instead of
+// 53 ms and the hash has the chip to itself for the rest.  The number of slices hardly matters (2..64: 61.6-63.0 ms);
+// splitting the blocks over two streams to fill each launch's tail did not help.  Alone the one-launch line kernel is
+// as fast, so it stays the default there.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kSkeinSlices = 8;
+
+template <int NW, bool ALIGNED16>
+__global__ void __launch_bounds__(CW_SKEIN_THREADS)
+skein_slice_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t src_stride, size_t nblocks, SkeinIV iv,
+                   uint8_t *__restrict__ digests, unsigned digest_bytes, uint64_t *__restrict__ state, size_t s_begin, size_t s_end)
+{
+    constexpr unsigned BB = NW * 8, SPL = 128 / BB, HS = SPL / 2;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nblocks) return;
+    const uint8_t *p = src + gid * src_stride;
+    const size_t nmsg = block_bytes / BB, total = nmsg + 1;
+    uint64_t *st = state + gid * NW;
+
+    uint64_t X[NW];
+    if (s_begin == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) X[i] = iv.w[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; i++) X[i] = st[i];
+    }
+    uint64_t t0 = (uint64_t)s_begin * BB, t1 = (s_begin == 0 ? T1_FIRST : 0) | T1_MSG;
+
+    uint64_t A[HS][NW], B[HS][NW], S[HS][NW];
+    auto fetch_half = [&](uint64_t (&dst)[HS][NW], size_t first) __attribute__((always_inline)) {
+#pragma unroll
+        for (unsigned j = 0; j < HS; j++) {
+            const size_t s = first + j;
+            const uint64_t keep = s < nmsg ? ~0ull : 0ull; // wave-uniform
+            load_words<NW, ALIGNED16>(dst[j], p + (s < nmsg ? s : nmsg - 1) * BB);
+#pragma unroll
+            for (int k = 0; k < NW; k++) dst[j][k] &= keep;
+        }
+    };
+    auto run_half = [&](uint64_t (&buf)[HS][NW], size_t first) {
+#pragma unroll
+        for (unsigned j = 0; j < HS; j++) {
+            const size_t s = first + j;
+            if (s < s_end) {
+                if (s + 1 < nmsg) {
+                    t0 += BB;
+                } else if (s + 1 == nmsg) {
+                    t0 += BB;
+                    t1 |= T1_FINAL;
+                } else {
+                    t0 = 8;
+                    t1 = T1_FIRST | T1_FINAL | T1_OUT;
+                }
+                Ubi<NW>::run(X, buf[j], t0, t1);
+                t1 &= ~T1_FIRST;
+            }
+        }
+    };
+    fetch_half(A, s_begin);
+    fetch_half(B, s_begin + HS);
+#pragma unroll 1
+    for (size_t first = s_begin; first < s_end; first += SPL) {
+        run_half(A, first);
+        fetch_half(A, first + SPL);
+        fetch_half(S, first + SPL + HS);
+        run_half(B, first + HS);
+#pragma unroll
+        for (unsigned j = 0; j < HS; j++)
+#pragma unroll
+            for (int k = 0; k < NW; k++) B[j][k] = S[j][k];
+    }
+
+    if (s_end < total) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) st[i] = X[i];
+        return;
+    }
+    uint8_t *out = digests + gid * digest_bytes;
+    if ((digest_bytes & 15) == 0) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(out);
+#pragma unroll
+        for (int k = 0; k < NW / 2; k++)
+            if ((unsigned)(16 * k) < digest_bytes)
+                o4[k] = make_uint4((uint32_t)X[2 * k], (uint32_t)(X[2 * k] >> 32), (uint32_t)X[2 * k + 1], (uint32_t)(X[2 * k + 1] >> 32));
+    } else {
+        for (unsigned k = 0; k < digest_bytes; k++) out[k] = (uint8_t)(X[k >> 3] >> (8 * (k & 7)));
+    }
+}
+
+namespace {
+struct SliceSpace { uint64_t *p = nullptr; size_t cap = 0; };
+std::mutex slice_lock;
+std::unordered_map<hipStream_t, SliceSpace> slice_map;
+}
+
+void skein_release_workspaces()
+{
+    std::lock_guard<std::mutex> g(slice_lock);
+    for (auto &kv : slice_map) if (kv.second.p) (void)hipFree(kv.second.p);
+    slice_map.clear();
+}
+
+bool skein_sliced_applies(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks)
+{
+    const size_t bb = (size_t)nw * 8;
+    return nblocks >= 4096 && block_bytes % bb == 0 && block_bytes / bb + 1 >= 256 &&
+           ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
+}
+
+hipError_t skein_sliced_launch(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
+                               uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
+{
+    const size_t bb = (size_t)nw * 8, total = block_bytes / bb + 1, spl = 128 / bb;
+    static const char *ns_env = getenv("CW_SKEIN_NSLICES"); // profiling knob
+    const size_t nsl = ns_env && atoi(ns_env) > 0 ? (size_t)atoi(ns_env) : kSkeinSlices;
+    size_t slice_steps = (total + nsl - 1) / nsl;
+    slice_steps = (slice_steps + spl - 1) / spl * spl;
+    uint64_t *state = nullptr;
+    {
+        std::lock_guard<std::mutex> g(slice_lock);
+        SliceSpace &w = slice_map[stream];
+        if (w.cap < nblocks * (size_t)nw) {
+            if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
+            w.p = nullptr; w.cap = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.p), nblocks * (size_t)nw * sizeof(uint64_t));
+            if (e != hipSuccess) return e;
+            w.cap = nblocks * (size_t)nw;
+        }
+        state = w.p;
+    }
+    const dim3 grid((unsigned)((nblocks + CW_SKEIN_THREADS - 1) / CW_SKEIN_THREADS)), block(CW_SKEIN_THREADS);
+    for (size_t b = 0; b < total; b += slice_steps) {
+        const size_t e = b + slice_steps < total ? b + slice_steps : total;
+        if (nw == 8)
+            hipLaunchKernelGGL((skein_slice_kernel<8, true>), grid, block, 0, stream, src, block_bytes, src_stride, nblocks, iv, digests,
+                               digest_bytes, state, b, e);
+        else
+            hipLaunchKernelGGL((skein_slice_kernel<4, true>), grid, block, 0, stream, src, block_bytes, src_stride, nblocks, iv, digests,
+                               digest_bytes, state, b, e);
+    }
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -509,3 +509,29 @@ def test_lz4_span_scan_with_strides_on_incompressible_blocks(cw, oracle):
         for i in range(nb):
             want = oracle.lz4_compress(raw[i * sstride: i * sstride + bs].tobytes())
             assert hz[i] == len(want) and hdst[i * dstride: i * dstride + len(want)].tobytes() == want, (bs, i)
+
+
+@pytest.mark.parametrize("alg,db,bs", [("skein512", 64, 16384), ("skein", 16, 8192), ("skein512", 64, 65536)])
+def test_fused_call_sliced_hash_equals_whole_block_hash(cw, oracle, alg, db, bs):
+    """From 4,096 blocks on, the fused call hashes long Skein messages in 8 launches of short-lived wavefronts
+    (chaining values handed on through a state array).  Same digests as the one-launch kernel and the oracle."""
+    import torch
+    nb = 4101 if bs < 65536 else 4097       # a last group that is not full
+    s = torch.cuda.current_stream().cuda_stream
+    src = torch.empty(nb * bs, dtype=torch.uint8, device="cuda")
+    cw.dev_gen_random(0xABCD, 7, nb, bs, src.data_ptr(), s)
+    stride = (cw.compress_bound("lz4", bs) + 15) // 16 * 16
+    dst = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    fused = torch.zeros(nb * db, dtype=torch.uint8, device="cuda")
+    plain = torch.zeros(nb * db, dtype=torch.uint8, device="cuda")
+    for _ in range(2):                      # twice: the state array is reused
+        fused.zero_()
+        cw.dev_hash_and_compress(alg, "lz4", src.data_ptr(), bs, nb, fused.data_ptr(), dst.data_ptr(), stride, sizes.data_ptr(), s)
+    cw.dev_hash(alg, src.data_ptr(), bs, nb, plain.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain)
+    host = src.cpu().numpy()
+    hd = fused.cpu().numpy()
+    for i in (0, 1, 63, 64, nb // 2 - 1, nb // 2, nb // 2 + 1, nb - 2, nb - 1):
+        assert hd[i * db:(i + 1) * db].tobytes() == _oracle_hash(oracle, alg, host[i * bs:(i + 1) * bs].tobytes()), i
