@@ -212,12 +212,19 @@ def main():
     # the codec reads the block and writes csize + 4
     csize = bytes_out / total_blocks
     alg_bytes = {"hash": bs + db, "comp": bs + csize + 4}
-    names = {"hash": {"skein512": "cw::skein_lines_kernel<8,true>", "skein": "cw::skein_lines_kernel<4,true>",
-                      "sha256mb": "cw::sha256_blocks_kernel<true,false>"}[args.hash],
-             "comp": "cw::lz4_scan_stream_kernel (+ cw::lz4_parse_kernel on queued blocks)" if args.comp == "lz4"
-                     else "cw::lzf_links_kernel + cw::lzf_chain_kernel" if bs <= 16384 else "cw::lzf_parse_kernel"}
+    # beside the codec, long Skein messages are hashed in 8 launches of cw::skein_slice_kernel (csrc/skein_kernels.hip);
+    # k_ms["hash"] spans all of them, so "launches" says how to compare it with a per-launch average from rocprofv3
+    nw = {"skein512": 8, "skein": 4}.get(args.hash, 0)
+    sliced = nw and nb >= 4096 and bs % (nw * 8) == 0 and bs // (nw * 8) + 1 >= 256 and os.environ.get("CW_SKEIN_SLICED", "1")[0] != "0"
+    launches = {"hash": 8 if sliced else 1, "comp": 1}
+    names = {"hash": (f"cw::skein_slice_kernel<{nw},true>" if sliced else
+                      {"skein512": "cw::skein_lines_kernel<8,true>", "skein": "cw::skein_lines_kernel<4,true>",
+                       "sha256mb": "cw::sha256_blocks_kernel<true,false>"}[args.hash]),
+             "comp": ("cw::lz4_scan_span_kernel (+ cw::lz4_parse_kernel on queued blocks)" if bs in (4096, 8192, 16384, 32768, 65536)
+                      else "cw::lz4_scan_stream_kernel (+ cw::lz4_parse_kernel on queued blocks)") if args.comp == "lz4"
+                     else "cw::lzf_links_kernel + cw::lzf_chain_kernel"}
     dom = max(k_ms, key=k_ms.get)
-    kernels = {k: {"ms_per_launch": round(k_ms[k], 3),
+    kernels = {k: {"ms_per_step": round(k_ms[k], 3), "launches_per_step": launches[k], "ms_per_launch": round(k_ms[k] / launches[k], 3),
                    "alg_GBps": round(alg_bytes[k] * nb / (k_ms[k] / 1e3) / 1e9, 1),
                    "ingest_GBps": round(bs * nb / (k_ms[k] / 1e3) / 1e9, 1)} for k in k_ms}
     achieved = alg_bytes[dom] * nb / (k_ms[dom] / 1e3) / 1e9
@@ -238,6 +245,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": names[dom],
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "launches_per_step": launches[dom], "ms_per_launch": round(k_ms[dom] / launches[dom], 3),
                      "alg_bytes_per_block": round(alg_bytes[dom], 1)},
         "kernels": dict(kernels, note="codec and hash run concurrently on two streams; durations overlap"),
         # the binding roof of the hash kernel is integer VALU issue, not HBM: instruction mix of one
