@@ -177,7 +177,7 @@ int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, 
     static const char *slice_env = getenv("CW_SKEIN_SLICED"); // CW_SKEIN_SLICED=0: whole-block hash kernel also in the fused call
     if (sliced && !(slice_env && slice_env[0] == '0') && (alg == CW_HASH_SKEIN512 || alg == CW_HASH_SKEIN256_128)) {
         const int nw = alg == CW_HASH_SKEIN512 ? 8 : 4;
-        if (cw::skein_sliced_applies(nw, d_src, bb, stride, n)) {
+        if (cw::skein_sliced_applies(nw, d_src, bb, stride, n, d_dig)) {
             e = cw::skein_sliced_launch(nw, d_src, bb, stride, n, nw == 8 ? g_iv512_512 : g_iv256_128, d_dig, nw == 8 ? 64 : 16, s);
             if (e != hipSuccess) return fail(CW_ERR_HIP, "hash launch: %s", hipGetErrorString(e));
             return CW_OK;

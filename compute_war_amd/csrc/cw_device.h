@@ -17,7 +17,8 @@ struct SkeinIV { uint64_t w[8]; };
 // host: chaining value after the configuration block (Skein_*_Init)
 void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv, uint64_t tree_info = 0);
 // sliced Skein for the fused call: the steps of every block in 8 launches (see skein_kernels.hip)
-bool skein_sliced_applies(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks);
+bool skein_sliced_applies(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks,
+                          const uint8_t *digests);
 hipError_t skein_sliced_launch(int state_words, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
                                uint8_t *digests, unsigned digest_bytes, hipStream_t stream);
 // tree hashing of every block (one wavefront per block, lane = leaf/node); digest = hash_bits / 8 bytes per block

@@ -475,11 +475,11 @@ void skein_release_workspaces()
     slice_map.clear();
 }
 
-bool skein_sliced_applies(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks)
+bool skein_sliced_applies(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const uint8_t *digests)
 {
     const size_t bb = (size_t)nw * 8;
     return nblocks >= 4096 && block_bytes % bb == 0 && block_bytes / bb + 1 >= 256 &&
-           ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
+           ((reinterpret_cast<uintptr_t>(src) | src_stride | reinterpret_cast<uintptr_t>(digests)) & 15) == 0;
 }
 
 hipError_t skein_sliced_launch(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const SkeinIV &iv,
