@@ -212,7 +212,7 @@ def main():
     # the codec reads the block and writes csize + 4
     csize = bytes_out / total_blocks
     alg_bytes = {"hash": bs + db, "comp": bs + csize + 4}
-    # beside the codec, long Skein messages are hashed in 8 launches of cw::skein_slice_kernel (csrc/skein_kernels.hip);
+    # long Skein messages are hashed in 8 launches of cw::skein_slice_kernel (csrc/skein_kernels.hip);
     # k_ms["hash"] spans all of them, so "launches" says how to compare it with a per-launch average from rocprofv3
     nw = {"skein512": 8, "skein": 4}.get(args.hash, 0)
     sliced = nw and nb >= 4096 and bs % (nw * 8) == 0 and bs // (nw * 8) + 1 >= 256 and os.environ.get("CW_SKEIN_SLICED", "1")[0] != "0"
@@ -255,7 +255,7 @@ def main():
                            "note": "peak = 1024 SIMDs x 4096 B per wavefront-call / 2.65 us; shared with the codec's VALU work "
                                    "when both kernels run"} if args.hash == "skein512" else None),
         # each kernel launched alone (not part of `value`): algorithmic bytes / duration against the HBM peak
-        "standalone": {k: {"ms_per_launch": round(solo_ms[k], 3), "ingest_GBps": round(bs * nb / (solo_ms[k] / 1e3) / 1e9, 1),
+        "standalone": {k: {"ms_per_step": round(solo_ms[k], 3), "launches_per_step": launches[k], "ingest_GBps": round(bs * nb / (solo_ms[k] / 1e3) / 1e9, 1),
                            "alg_GBps": round(alg_bytes[k] * nb / (solo_ms[k] / 1e3) / 1e9, 1),
                            "hbm_frac": round(alg_bytes[k] * nb / (solo_ms[k] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)} for k in solo_ms},
         "parity_spot_check": spot,

@@ -168,13 +168,13 @@ int check_block(size_t block_bytes)
     return CW_OK;
 }
 
-// sliced: the caller runs codec wavefronts beside the hash; long Skein messages are then hashed in several launches
+// sliced: long Skein messages (>= 256 steps, >= 4096 blocks) are hashed in several launches of short-lived wavefronts
 int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, uint8_t *d_dig, hipStream_t s, bool lean = false,
              bool sliced = false)
 {
     hipError_t e;
     ProfScope prof(PROF_HASH, s);
-    static const char *slice_env = getenv("CW_SKEIN_SLICED"); // CW_SKEIN_SLICED=0: whole-block hash kernel also in the fused call
+    static const char *slice_env = getenv("CW_SKEIN_SLICED"); // CW_SKEIN_SLICED=0: always the one-launch hash kernel (profiling knob)
     if (sliced && !(slice_env && slice_env[0] == '0') && (alg == CW_HASH_SKEIN512 || alg == CW_HASH_SKEIN256_128)) {
         const int nw = alg == CW_HASH_SKEIN512 ? 8 : 4;
         if (cw::skein_sliced_applies(nw, d_src, bb, stride, n, d_dig)) {
@@ -293,7 +293,9 @@ int cw_dev_hash(int hash_alg, const void *d_src, size_t block_bytes, size_t src_
     if (!d_src || !d_digests) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
     if ((rc = check_block(block_bytes)) != CW_OK) return rc;
     if (src_stride < block_bytes) return fail(CW_ERR_BAD_ARG, "src_stride < block_bytes");
-    return dev_hash(hash_alg, (const uint8_t *)d_src, block_bytes, src_stride, nblocks, (uint8_t *)d_digests, (hipStream_t)stream);
+    // long Skein messages in sliced launches here too: alone they are as fast as the one-launch kernel (46.6 ms per Mi blocks
+    // either way, slightly ahead on small batches), and the hot kernel is then the same with and without a codec beside it
+    return dev_hash(hash_alg, (const uint8_t *)d_src, block_bytes, src_stride, nblocks, (uint8_t *)d_digests, (hipStream_t)stream, false, true);
 }
 
 int cw_dev_compress(int comp_alg, const void *d_src, size_t block_bytes, size_t src_stride, size_t nblocks, void *d_dst,

@@ -369,13 +369,14 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Sliced launches for the fused call: the steps of a block are cut into kSkeinSlices launches of short-lived wavefronts
+// Sliced launches: the steps of a block are cut into kSkeinSlices launches of short-lived wavefronts
 // that hand the chaining values on through a state array (kernel boundaries order and publish it: no flags, no
 // spinning -- a persistent-grid version with in-kernel dependencies lost to the oldest-first issue order).
 // Beside the codec this is 61.6 instead of 64.5 ms per Mi blocks of 64 KiB: the scan then finishes after 33 instead of
 // 53 ms and the hash has the chip to itself for the rest.  The number of slices hardly matters (2..64: 61.6-63.0 ms);
-// splitting the blocks over two streams to fill each launch's tail did not help.  Alone the one-launch line kernel is
-// as fast, so it stays the default there.
+// splitting the blocks over two streams to fill each launch's tail did not help.  Without a codec beside it the sliced
+// hash is as fast as the one-launch line kernel (46.6 ms per Mi blocks, a little ahead on small batches), so it is used
+// there too; the line kernel serves batches below 4,096 blocks and short messages.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kSkeinSlices = 8;
 

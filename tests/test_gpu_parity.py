@@ -513,8 +513,9 @@ def test_lz4_span_scan_with_strides_on_incompressible_blocks(cw, oracle):
 
 @pytest.mark.parametrize("alg,db,bs", [("skein512", 64, 16384), ("skein", 16, 8192), ("skein512", 64, 65536)])
 def test_fused_call_sliced_hash_equals_whole_block_hash(cw, oracle, alg, db, bs):
-    """From 4,096 blocks on, the fused call hashes long Skein messages in 8 launches of short-lived wavefronts
-    (chaining values handed on through a state array).  Same digests as the one-launch kernel and the oracle."""
+    """From 4,096 blocks on, long Skein messages are hashed in 8 launches of short-lived wavefronts (chaining values
+    handed on through a state array), with and without a codec beside them.  Same digests as the one-launch kernel
+    (smaller batches) and the oracle."""
     import torch
     nb = 4101 if bs < 65536 else 4097       # a last group that is not full
     s = torch.cuda.current_stream().cuda_stream
@@ -528,9 +529,13 @@ def test_fused_call_sliced_hash_equals_whole_block_hash(cw, oracle, alg, db, bs)
     for _ in range(2):                      # twice: the state array is reused
         fused.zero_()
         cw.dev_hash_and_compress(alg, "lz4", src.data_ptr(), bs, nb, fused.data_ptr(), dst.data_ptr(), stride, sizes.data_ptr(), s)
-    cw.dev_hash(alg, src.data_ptr(), bs, nb, plain.data_ptr(), s)
+    alone = torch.zeros(nb * db, dtype=torch.uint8, device="cuda")
+    cw.dev_hash(alg, src.data_ptr(), bs, nb, alone.data_ptr(), s)                 # sliced as well (>= 4096 blocks)
+    for first in range(0, nb, 2048):                                              # < 4096 blocks per call: the one-launch kernel
+        n = min(2048, nb - first)
+        cw.dev_hash(alg, src.data_ptr() + first * bs, bs, n, plain.data_ptr() + first * db, s)
     torch.cuda.synchronize()
-    assert torch.equal(fused, plain)
+    assert torch.equal(fused, plain) and torch.equal(alone, plain)
     host = src.cpu().numpy()
     hd = fused.cpu().numpy()
     for i in (0, 1, 63, 64, nb // 2 - 1, nb // 2, nb // 2 + 1, nb - 2, nb - 1):
