@@ -1,10 +1,12 @@
 // cw_api.hip -- host side of libcwhc.so: the C ABI of include/cw_hashcompress.h over the HIP kernels.
 //
-// Structure: a process-wide device selection (cw_init = the reference's empty initializeGpu(),
-// src/hashandcompress/HashAndCompress.cpp:95-98), one lazily created context per calling host thread
-// (own HIP stream + growable device staging buffers, because the reference invokes its slots from
-// --c-threads workers with no locking, :398-402), the HashOffload batch object (HashOffload.h:13-64)
-// and the single consumer thread that drains it (hashing_offload_entry_point, :160-183).
+// Structure: a set of initialised devices (cw_init = the reference's empty initializeGpu(),
+// src/hashandcompress/HashAndCompress.cpp:95-98) with one "current device" per calling host thread (cw_set_device;
+// threads that never choose use the first initialised device), one lazily created context per (thread, device) --
+// own HIP streams + growable device/pinned staging buffers, because the reference invokes its slots from --c-threads
+// workers with no locking, :398-402 --, the pipelined host batch path (what HashOffload::Start()/Complete() were meant
+// to be, HashOffload.h:26-40), the HashOffload batch object itself (HashOffload.h:13-64) and the single consumer
+// thread that drains it (hashing_offload_entry_point, :160-183).
 //
 // No CPU fallback exists: every compute path ends in a kernel launch or an error.
 
@@ -17,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -64,19 +67,35 @@ struct ProfScope { // brackets the launches made during its lifetime on `stream`
     }
 };
 
-// ---- process-wide state -----------------------------------------------------------------------
+// ---- devices ----------------------------------------------------------------------------------------
+constexpr int kMaxDevices = 16;
 std::mutex g_lock;
-std::atomic<int> g_device{-1};
-cw::SkeinIV g_iv512_512, g_iv256_128;
+std::atomic<int> g_default{-1};        // first initialised device: what threads use that never chose one
+std::atomic<uint32_t> g_mask{0};       // initialised devices
+thread_local int t_device = -1;        // the calling thread's device (cw_init / cw_set_device), -1 = g_default
+cw::SkeinIV g_iv512_512, g_iv256_128;  // host-computed, device independent
 std::atomic<size_t> g_block_size{4096}; // the reference's global blockSize (:89)
 
-int ensure_init()
+int current_device()
 {
-    if (g_device.load(std::memory_order_acquire) >= 0) return CW_OK;
-    return cw_init(0);
+    const int d = t_device;
+    return d >= 0 && ((g_mask.load(std::memory_order_acquire) >> d) & 1u) ? d : g_default.load(std::memory_order_acquire);
 }
 
-// ---- per-thread context -------------------------------------------------------------------------
+// every entry point: initialise on first use and make the library's device the calling thread's HIP device
+int ensure_init()
+{
+    int d = current_device();
+    if (d < 0) {
+        const int rc = cw_init(t_device >= 0 ? t_device : 0);
+        if (rc != CW_OK) return rc;
+        d = current_device();
+    }
+    HIP_TRY(hipSetDevice(d));
+    return CW_OK;
+}
+
+// ---- per-(thread, device) context ---------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -93,7 +112,7 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-struct PinnedBuf { // host staging for the packed stream (one large D2H instead of one per block)
+struct PinnedBuf { // page-locked host staging: the only kind of host memory a copy engine reads or writes at bus speed
     void *p = nullptr;
     size_t cap = 0;
     int reserve(size_t n)
@@ -110,55 +129,94 @@ struct PinnedBuf { // host staging for the packed stream (one large D2H instead 
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-// fork/join helper for cw_dev_hash_and_compress: the codec runs on a side stream beside the hash
-struct SideStream {
-    hipStream_t side = nullptr;
+// one chunk of the host batch path in flight: device buffers, pinned staging, the events of its three stages
+constexpr int kSlots = 3;
+struct Slot {
+    DevBuf src, dst, pack, sizes, offs, dig;
+    PinnedBuf h_src, h_meta, h_pack;
+    hipStream_t stream = nullptr, side = nullptr; // this chunk's kernels: codec on `stream`, hash beside it on `side`
     hipEvent_t fork = nullptr, join = nullptr;
-    int device = -1;
+    hipEvent_t ev_h2d = nullptr, ev_meta = nullptr, ev_payload = nullptr;
+    size_t first = 0, n = 0;
+    uint64_t total = 0;
     int open()
     {
-        const int dev = g_device.load();
-        if (side && device == dev) return CW_OK;
+        if (ev_h2d) return CW_OK;
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
+        HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_meta, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_payload, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_h2d, hipEventDisableTiming));
+        return CW_OK;
+    }
+    void release()
+    {
+        src.release(); dst.release(); pack.release(); sizes.release(); offs.release(); dig.release();
+        h_src.release(); h_meta.release(); h_pack.release();
+        if (stream) (void)hipStreamDestroy(stream);
+        if (side) (void)hipStreamDestroy(side);
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (ev_meta) (void)hipEventDestroy(ev_meta);
+        if (ev_payload) (void)hipEventDestroy(ev_payload);
+        if (ev_h2d) (void)hipEventDestroy(ev_h2d);
+        stream = side = nullptr; fork = join = ev_meta = ev_payload = ev_h2d = nullptr;
+    }
+};
+
+struct ThreadCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;            // kernels of the host-buffer entry points
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr; // the two copy directions of the pipelined batch path
+    // fork/join for the fused call: the hash runs on `side` beside the codec on the caller's stream
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    DevBuf src, dst, dig, sizes;             // unpipelined helpers (decompress, tree hash)
+    Slot slot[kSlots];
+    int open(int dev)
+    {
+        if (stream) return CW_OK;
+        device = dev;
         HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s_d2h, hipStreamNonBlocking));
         int least = 0, greatest = 0; // the hash is the long, ALU-bound kernel: it yields dispatch slots to the codec
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
         HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-        device = dev;
-        return CW_OK;
-    }
-    ~SideStream()
-    {
-        if (!side) return;
-        (void)hipEventDestroy(fork); (void)hipEventDestroy(join); (void)hipStreamDestroy(side);
-    }
-};
-thread_local SideStream t_side;
-
-struct ThreadCtx {
-    hipStream_t stream = nullptr;
-    DevBuf src, dst, dig, sizes, pack, offs;
-    PinnedBuf hpack;
-    bool ready = false;
-    int open()
-    {
-        if (ready) return CW_OK;
-        int rc = ensure_init();
-        if (rc != CW_OK) return rc;
-        HIP_TRY(hipSetDevice(g_device.load()));
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        ready = true;
         return CW_OK;
     }
     ~ThreadCtx()
     {
-        if (!ready) return;
-        src.release(); dst.release(); dig.release(); sizes.release(); pack.release(); offs.release(); hpack.release();
-        (void)hipStreamDestroy(stream);
+        if (!stream) return;
+        (void)hipSetDevice(device);
+        src.release(); dst.release(); dig.release(); sizes.release();
+        for (Slot &s : slot) s.release();
+        (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
+        (void)hipStreamDestroy(side); (void)hipStreamDestroy(s_h2d); (void)hipStreamDestroy(s_d2h); (void)hipStreamDestroy(stream);
     }
 };
-thread_local ThreadCtx t_ctx;
+struct ThreadCtxSet { std::unique_ptr<ThreadCtx> of[kMaxDevices]; };
+thread_local ThreadCtxSet t_ctxs;
+
+// the calling thread's context on its current device (created on first use)
+int thread_ctx(ThreadCtx **out)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    const int d = current_device();
+    std::unique_ptr<ThreadCtx> &c = t_ctxs.of[d];
+    if (!c) c.reset(new ThreadCtx);
+    if ((rc = c->open(d)) != CW_OK) return rc;
+    *out = c.get();
+    return CW_OK;
+}
 
 const size_t kMaxChunkBytes = (size_t)256 << 20; // host-API staging granularity
 
@@ -210,6 +268,8 @@ int dev_compress(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t
     return CW_OK;
 }
 
+thread_local char t_kernels[2][192] = {"", ""};
+
 [[noreturn]] void die(const char *what)
 {
     fprintf(stderr, "libcwhc: %s failed: %s\n", what, t_err);
@@ -217,6 +277,13 @@ int dev_compress(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t
 }
 
 } // namespace
+
+void cw::note_kernels(int kind, const char *names)
+{
+    if (kind < 0 || kind > 1) return;
+    strncpy(t_kernels[kind], names, sizeof t_kernels[kind] - 1);
+    t_kernels[kind][sizeof t_kernels[kind] - 1] = 0;
+}
 
 extern "C" {
 
@@ -231,33 +298,48 @@ int cw_device_count(void)
 int cw_init(int device)
 {
     std::lock_guard<std::mutex> g(g_lock);
-    if (g_device.load() >= 0) return CW_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(CW_ERR_NO_DEVICE, "no HIP device (%s)", hipGetErrorString(e));
-    if (device < 0 || device >= n) return fail(CW_ERR_BAD_ARG, "device %d out of range (count %d)", device, n);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(CW_ERR_NO_DEVICE, "device %d is %s; libcwhc is built for gfx950 only", device, prop.gcnArchName);
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(CW_ERR_BAD_ARG, "device %d out of range (count %d)", device, n);
+    if (!((g_mask.load() >> device) & 1u)) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(CW_ERR_NO_DEVICE, "device %d is %s; libcwhc is built for gfx950 only", device, prop.gcnArchName);
+        if (g_mask.load() == 0) {
+            cw::skein_compute_iv(8, 512, &g_iv512_512);
+            cw::skein_compute_iv(4, 128, &g_iv256_128);
+        }
+        g_mask.fetch_or(1u << device, std::memory_order_release);
+        if (g_default.load() < 0) g_default.store(device, std::memory_order_release);
+    }
     HIP_TRY(hipSetDevice(device));
-    cw::skein_compute_iv(8, 512, &g_iv512_512);
-    cw::skein_compute_iv(4, 128, &g_iv256_128);
-    g_device.store(device, std::memory_order_release);
+    t_device = device; // the calling thread works on this device from now on
     return CW_OK;
 }
+
+int cw_set_device(int device) { return cw_init(device); }
+int cw_get_device(void) { return current_device(); }
 
 void cw_shutdown(void)
 {
     cw_offload_thread_stop();
     std::lock_guard<std::mutex> g(g_lock);
-    if (g_device.load() < 0) return;
-    (void)hipDeviceSynchronize();
+    const uint32_t mask = g_mask.load();
+    if (!mask) return;
+    for (int d = 0; d < kMaxDevices; d++)
+        if ((mask >> d) & 1u) {
+            (void)hipSetDevice(d);
+            (void)hipDeviceSynchronize();
+        }
     cw::skein_release_workspaces();
     cw::lz4_release_workspaces();
     cw::lzf_release_workspaces();
     cw::pack_release_workspaces();
-    g_device.store(-1);
+    g_mask.store(0);
+    g_default.store(-1);
+    t_device = -1;
 }
 
 const char *cw_last_error(void) { return t_err; }
@@ -311,37 +393,43 @@ int cw_dev_compress(int comp_alg, const void *d_src, size_t block_bytes, size_t 
                         (hipStream_t)stream);
 }
 
+// ProcessBlock (:243-257) compresses, then hashes; the two only share their read-only input, so they run side by
+// side: the codec (latency/memory bound, few issue slots, persistent grid) goes first on the caller's stream so its
+// workgroups are resident before the hash (pure integer VALU, one long-lived wavefront per 64 blocks) fills the rest of
+// every CU from the context's low-priority side stream; the side stream is joined before the call's work counts as done.
+static int dev_fused(hipStream_t side, hipEvent_t fork, hipEvent_t join, int hash_alg, int comp_alg, const uint8_t *d_src, size_t block_bytes, size_t src_stride, size_t nblocks,
+                     uint8_t *d_digests, uint8_t *d_dst, size_t dst_stride, uint32_t *d_sizes, hipStream_t main_s)
+{
+    int rc;
+    static const char *serial = getenv("CW_SERIAL"); // CW_SERIAL=1: both kernels on the caller's stream (profiling knob)
+    if (serial && serial[0] == '1') {
+        rc = dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, main_s);
+        return rc == CW_OK ? dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, main_s, false, true) : rc;
+    }
+    HIP_TRY(hipEventRecord(fork, main_s));
+    HIP_TRY(hipStreamWaitEvent(side, fork, 0));
+    rc = dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, main_s);
+    if (rc == CW_OK) rc = dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, side, false, true);
+    HIP_TRY(hipEventRecord(join, side));
+    HIP_TRY(hipStreamWaitEvent(main_s, join, 0));
+    return rc;
+}
+
 int cw_dev_hash_and_compress(int hash_alg, int comp_alg, const void *d_src, size_t block_bytes, size_t src_stride,
                              size_t nblocks, void *d_digests, void *d_dst, size_t dst_stride, uint32_t *d_sizes, void *stream)
 {
-    // ProcessBlock (:243-257) compresses, then hashes; the two only share their read-only input, so they run
-    // side by side: the codec (latency/memory bound, few issue slots, persistent grid) goes first on the
-    // caller's stream so its workgroups are resident before the hash (pure integer VALU, one long-lived
-    // wavefront per 64 blocks) fills the rest of every CU from a low-priority side stream; the side stream
-    // is joined before this call's work counts as done.
     if (comp_alg == CW_COMP_NONE) return cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, stream);
     if (hash_alg == CW_HASH_NONE)
         return cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
-    int rc = ensure_init();
+    ThreadCtx *c;
+    int rc = thread_ctx(&c);
     if (rc != CW_OK) return rc;
-    static const char *serial = getenv("CW_SERIAL"); // CW_SERIAL=1: both kernels on the caller's stream (profiling knob)
-    if (serial && serial[0] == '1') {
-        rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
-        return rc == CW_OK ? cw_dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, stream) : rc;
-    }
-    if ((rc = t_side.open()) != CW_OK) return rc;
-    hipStream_t main_s = (hipStream_t)stream;
-    HIP_TRY(hipEventRecord(t_side.fork, main_s));
-    HIP_TRY(hipStreamWaitEvent(t_side.side, t_side.fork, 0));
-    rc = cw_dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, stream);
-    if (rc == CW_OK) {
-        if (!d_digests) rc = fail(CW_ERR_BAD_ARG, "NULL device pointer");
-        else rc = dev_hash(hash_alg, (const uint8_t *)d_src, block_bytes, src_stride ? src_stride : block_bytes, nblocks, (uint8_t *)d_digests,
-                           t_side.side, false, true);
-    }
-    HIP_TRY(hipEventRecord(t_side.join, t_side.side));
-    HIP_TRY(hipStreamWaitEvent(main_s, t_side.join, 0));
-    return rc;
+    if (nblocks == 0) return CW_OK;
+    if (!d_src || !d_dst || !d_sizes || !d_digests) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
+    if ((rc = check_block(block_bytes)) != CW_OK) return rc;
+    if (src_stride < block_bytes) return fail(CW_ERR_BAD_ARG, "src_stride < block_bytes");
+    return dev_fused(c->side, c->fork, c->join, hash_alg, comp_alg, (const uint8_t *)d_src, block_bytes, src_stride, nblocks, (uint8_t *)d_digests, (uint8_t *)d_dst,
+                     dst_stride, d_sizes, (hipStream_t)stream);
 }
 
 int cw_dev_decompress(int comp_alg, const void *d_comp, size_t comp_stride, const uint32_t *d_sizes, size_t nblocks, void *d_dst,
@@ -399,6 +487,17 @@ int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_
     return CW_OK;
 }
 
+int cw_dev_gen_mixed(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, void *d_dst, void *stream)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    if (!d_dst) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
+    if (block_bytes % 16 || block_bytes > CW_MAX_BLOCK_BYTES) return fail(CW_ERR_BAD_ARG, "block_bytes must be a multiple of 16, <= 65536");
+    hipError_t e = cw::gen_mixed_launch(seed, first_block, nblocks, block_bytes, (uint8_t *)d_dst, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(CW_ERR_HIP, "gen launch: %s", hipGetErrorString(e));
+    return CW_OK;
+}
+
 int cw_dev_sum_sizes(const uint32_t *d_sizes, size_t nblocks, uint32_t raw_bytes, uint64_t *d_totals, void *stream)
 {
     int rc = ensure_init();
@@ -406,6 +505,38 @@ int cw_dev_sum_sizes(const uint32_t *d_sizes, size_t nblocks, uint32_t raw_bytes
     if (!d_sizes || !d_totals) return fail(CW_ERR_BAD_ARG, "NULL device pointer");
     hipError_t e = cw::sum_sizes_launch(d_sizes, nblocks, raw_bytes, d_totals, (hipStream_t)stream);
     if (e != hipSuccess) return fail(CW_ERR_HIP, "sum launch: %s", hipGetErrorString(e));
+    return CW_OK;
+}
+
+// plain device memory for C callers of the cw_dev_* functions (the host programs link no HIP runtime themselves)
+void *cw_dev_alloc(size_t bytes)
+{
+    if (ensure_init() != CW_OK) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { fail(CW_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void cw_dev_free(void *d_p) { if (d_p) (void)hipFree(d_p); }
+int cw_dev_upload(void *d_dst, const void *src, size_t bytes)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return CW_OK;
+}
+int cw_dev_download(void *dst, const void *d_src, size_t bytes)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return CW_OK;
+}
+int cw_dev_synchronize(void)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return CW_OK;
 }
 
@@ -428,88 +559,285 @@ int cw_profile_read(double ms_sum[3], unsigned count[3], int reset)
     return CW_OK;
 }
 
+int cw_profile_kernels(int kind, char *buf, size_t cap)
+{
+    if (kind < 0 || kind > 1 || !buf || cap == 0) return fail(CW_ERR_BAD_ARG, "cw_profile_kernels: kind 0 (codec) or 1 (hash), a buffer");
+    strncpy(buf, t_kernels[kind], cap - 1);
+    buf[cap - 1] = 0;
+    return CW_OK;
+}
+
 // ---- batched host API ------------------------------------------------------------------------------------
+// The pipelined batch path: what HashOffload::Start() ("xfer data, load kernel") and Complete() ("wait for and reap the
+// results", HashOffload.h:26-40) were meant to be, for a whole batch.  The batch is cut into chunks and three of them are
+// in flight at any time, each in a Slot with its own device buffers, pinned staging and streams:
+//   s_h2d      chunk k+1 crosses the bus host -> device
+//   slot.stream / slot.side   chunk k: codec and hash side by side, then the slots are packed into one stream on the device
+//              (pack_kernels.hip) so that only the compressed bytes cross the bus back; sizes, the total and the digests
+//              follow on the same stream
+//   s_d2h      chunk k-1's packed payload crosses device -> host
+//   host       meanwhile the calling thread moves chunk k-2's payload from pinned staging into the caller's slots.
+// Host memory the copy engines touch directly must be page-locked: a caller's buffer that is (cw_host_alloc /
+// cw_host_register) is used in place, anything else goes through the slot's pinned staging with one memcpy.
+namespace {
+struct HostJob {
+    int hash_alg, comp_alg;
+    const uint8_t *src; size_t bb, nblocks;
+    uint8_t *digests; uint8_t *dst; size_t dst_stride; uint32_t *sizes;
+    uint8_t *packed; size_t packed_cap; uint64_t *offsets; // packed-output form (dst == NULL)
+    bool do_hash, do_comp, src_pinned, packed_pinned;
+    size_t db, d_stride;
+    uint64_t packed_off;
+};
+
+bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+size_t meta_off_total(size_t n) { return (n * 4 + 7) & ~(size_t)7; }
+size_t meta_off_dig(size_t n) { return meta_off_total(n) + 8; }
+
+int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack);
+
+int pipe_issue(ThreadCtx &c, HostJob &j, Slot &s, size_t first, size_t n)
+{
+    int rc = slot_reserve(j, s, n, !j.src_pinned, !(j.packed && j.packed_pinned));
+    if (rc != CW_OK) return rc;
+    s.first = first; s.n = n; s.total = 0;
+    const size_t bytes = n * j.bb;
+    const uint8_t *hsrc = j.src + first * j.bb;
+    if (!j.src_pinned && bytes) {
+        memcpy(s.h_src.p, hsrc, bytes);
+        hsrc = (const uint8_t *)s.h_src.p;
+    }
+    if (bytes) HIP_TRY(hipMemcpyAsync(s.src.p, hsrc, bytes, hipMemcpyHostToDevice, c.s_h2d));
+    HIP_TRY(hipEventRecord(s.ev_h2d, c.s_h2d));
+    HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_h2d, 0));
+    uint8_t *meta = (uint8_t *)s.h_meta.p;
+    if (j.do_comp && j.do_hash)
+        rc = dev_fused(s.side, s.fork, s.join, j.hash_alg, j.comp_alg, (const uint8_t *)s.src.p, j.bb, j.bb, n, (uint8_t *)s.dig.p, (uint8_t *)s.dst.p,
+                       j.d_stride, (uint32_t *)s.sizes.p, s.stream);
+    else if (j.do_comp)
+        rc = dev_compress(j.comp_alg, (const uint8_t *)s.src.p, j.bb, j.bb, n, (uint8_t *)s.dst.p, j.d_stride, (uint32_t *)s.sizes.p, s.stream);
+    else
+        rc = dev_hash(j.hash_alg, (const uint8_t *)s.src.p, j.bb, j.bb, n, (uint8_t *)s.dig.p, s.stream, false, true);
+    if (rc != CW_OK) return rc;
+    if (j.do_comp) {
+        hipError_t pe = cw::pack_launch((const uint8_t *)s.dst.p, j.d_stride, (const uint32_t *)s.sizes.p, n, (uint8_t *)s.pack.p, (uint64_t *)s.offs.p,
+                                        s.stream);
+        if (pe != hipSuccess) return fail(CW_ERR_HIP, "pack launch: %s", hipGetErrorString(pe));
+        HIP_TRY(hipMemcpyAsync(meta, s.sizes.p, n * 4, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipMemcpyAsync(meta + meta_off_total(n), (const uint64_t *)s.offs.p + n, 8, hipMemcpyDeviceToHost, s.stream));
+    }
+    if (j.do_hash) HIP_TRY(hipMemcpyAsync(meta + meta_off_dig(n), s.dig.p, n * j.db, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(hipEventRecord(s.ev_meta, s.stream));
+    return CW_OK;
+}
+
+// sizes, total and digests of the slot's chunk are on the host: hand them out and start the payload's way back
+int pipe_reap(ThreadCtx &c, HostJob &j, Slot &s)
+{
+    HIP_TRY(hipEventSynchronize(s.ev_meta));
+    const uint8_t *meta = (const uint8_t *)s.h_meta.p;
+    const size_t n = s.n;
+    if (j.do_hash) memcpy(j.digests + s.first * j.db, meta + meta_off_dig(n), n * j.db);
+    if (j.do_comp) {
+        const uint32_t *sz = (const uint32_t *)meta;
+        memcpy(j.sizes + s.first, sz, n * 4);
+        memcpy(&s.total, meta + meta_off_total(n), 8);
+        if (j.dst) {
+            for (size_t i = 0; i < n; i++)
+                if (sz[i] > j.dst_stride) return fail(CW_ERR_BAD_ARG, "block %zu: %u bytes exceed dst_stride %zu", s.first + i, sz[i], j.dst_stride);
+        } else {
+            if (j.packed_off + s.total > j.packed_cap)
+                return fail(CW_ERR_BAD_ARG, "packed stream needs more than the %zu bytes provided", j.packed_cap);
+            uint64_t o = j.packed_off;
+            for (size_t i = 0; i < n; i++) { j.offsets[s.first + i] = o; o += sz[i]; }
+        }
+        HIP_TRY(hipStreamWaitEvent(c.s_d2h, s.ev_meta, 0));
+        if (s.total) {
+            void *to = j.packed && j.packed_pinned ? (void *)(j.packed + j.packed_off) : s.h_pack.p;
+            HIP_TRY(hipMemcpyAsync(to, s.pack.p, s.total, hipMemcpyDeviceToHost, c.s_d2h));
+        }
+        HIP_TRY(hipEventRecord(s.ev_payload, c.s_d2h));
+        if (!j.dst) { s.first = (size_t)j.packed_off; j.packed_off += s.total; } // first now = the chunk's place in the packed stream
+    }
+    return CW_OK;
+}
+
+// the payload of the slot's chunk is in pinned staging: move it to where the caller wants it
+int pipe_finish(HostJob &j, Slot &s)
+{
+    if (!j.do_comp) return CW_OK;
+    HIP_TRY(hipEventSynchronize(s.ev_payload));
+    if (!s.total) return CW_OK;
+    const uint8_t *from = (const uint8_t *)s.h_pack.p;
+    if (j.dst) {
+        const uint32_t *sz = (const uint32_t *)s.h_meta.p; // still this chunk's: the slot is not reused before this returns
+        for (size_t i = 0; i < s.n; i++) {
+            memcpy(j.dst + (s.first + i) * j.dst_stride, from, sz[i]);
+            from += sz[i];
+        }
+    } else if (!j.packed_pinned) {
+        memcpy(j.packed + s.first, from, s.total);
+    }
+    return CW_OK;
+}
+
+void pipe_drain(ThreadCtx &c)
+{
+    (void)hipStreamSynchronize(c.s_h2d);
+    for (Slot &s : c.slot) { if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamSynchronize(s.side); } }
+    (void)hipStreamSynchronize(c.s_d2h);
+}
+
+// chunk: large enough that one chunk's kernels fill a good part of the GPU (a 64 KiB Skein block is a 3 ms serial chain
+// whatever the batch), small enough that three of them pipeline; CW_HOST_CHUNK_MB overrides
+size_t pipeline_chunk(size_t bb, size_t nblocks)
+{
+    static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
+    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (bb > 16384 ? (size_t)128 << 20 : (size_t)64 << 20);
+    size_t chunk = chunk_bytes / (bb ? bb : 1);
+    if (chunk == 0) chunk = 1;
+    if (chunk > nblocks) chunk = nblocks;
+    if (nblocks > chunk && nblocks < 3 * chunk) chunk = (nblocks + 2) / 3; // a small batch still gets three stages
+    return chunk ? chunk : 1;
+}
+
+// device buffers, pinned staging, streams and events of one slot for chunks of n blocks (idempotent; grows only)
+int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack)
+{
+    int rc = s.open();
+    if (rc != CW_OK) return rc;
+    if ((rc = s.src.reserve(n * j.bb + 16)) != CW_OK) return rc;
+    if (j.do_hash && (rc = s.dig.reserve(n * j.db)) != CW_OK) return rc;
+    if (j.do_comp && ((rc = s.dst.reserve(n * j.d_stride)) != CW_OK || (rc = s.sizes.reserve(n * 4)) != CW_OK ||
+                      (rc = s.pack.reserve(n * j.d_stride)) != CW_OK || (rc = s.offs.reserve((n + 1) * 8)) != CW_OK))
+        return rc;
+    if ((rc = s.h_meta.reserve(meta_off_dig(n) + n * j.db)) != CW_OK) return rc;
+    if (j.do_comp && stage_pack && (rc = s.h_pack.reserve(n * j.d_stride)) != CW_OK) return rc;
+    if (stage_src && n * j.bb && (rc = s.h_src.reserve(n * j.bb)) != CW_OK) return rc;
+    return CW_OK;
+}
+
+int host_pipeline(HostJob &j)
+{
+    ThreadCtx *cp;
+    int rc = thread_ctx(&cp);
+    if (rc != CW_OK) return rc;
+    ThreadCtx &c = *cp;
+    if (j.nblocks == 0 || (!j.do_hash && !j.do_comp)) { if (j.offsets) j.offsets[0] = 0; return CW_OK; }
+    const size_t chunk = pipeline_chunk(j.bb, j.nblocks);
+    const size_t nchunks = (j.nblocks + chunk - 1) / chunk;
+    j.src_pinned = is_pinned(j.src);
+    j.packed_pinned = j.packed && is_pinned(j.packed);
+    j.packed_off = 0;
+    for (size_t k = 0; k < nchunks + 2 && rc == CW_OK; k++) {
+        if (k < nchunks) {
+            const size_t first = k * chunk;
+            rc = pipe_issue(c, j, c.slot[k % kSlots], first, j.nblocks - first < chunk ? j.nblocks - first : chunk);
+        }
+        if (rc == CW_OK && k >= 1 && k - 1 < nchunks) rc = pipe_reap(c, j, c.slot[(k - 1) % kSlots]);
+        if (rc == CW_OK && k >= 2) rc = pipe_finish(j, c.slot[(k - 2) % kSlots]);
+    }
+    if (rc != CW_OK) { pipe_drain(c); return rc; }
+    if (j.offsets) j.offsets[j.nblocks] = j.packed_off;
+    return CW_OK;
+}
+
+int host_job_init(HostJob &j, int hash_alg, int comp_alg, const void *src, size_t block_bytes, size_t nblocks, void *digests, bool want_comp)
+{
+    memset(&j, 0, sizeof j);
+    j.hash_alg = hash_alg; j.comp_alg = comp_alg; j.src = (const uint8_t *)src; j.bb = block_bytes; j.nblocks = nblocks;
+    j.digests = (uint8_t *)digests;
+    j.do_hash = hash_alg != CW_HASH_NONE && digests != nullptr;
+    j.do_comp = comp_alg != CW_COMP_NONE && want_comp;
+    if (nblocks == 0 || (!j.do_hash && !j.do_comp)) return CW_OK;
+    if (!src && block_bytes) return fail(CW_ERR_BAD_ARG, "NULL src");
+    int rc = check_block(block_bytes);
+    if (rc != CW_OK) return rc;
+    j.db = cw_digest_bytes(hash_alg);
+    if (j.do_hash && j.db == 0) return fail(CW_ERR_BAD_ARG, "unknown hash algorithm %d", hash_alg);
+    const size_t bound = j.do_comp ? cw_compress_bound(comp_alg, block_bytes) : 0;
+    if (j.do_comp && bound == 0) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
+    if (j.do_comp && block_bytes == 0) return fail(CW_ERR_BAD_ARG, "compression needs block_bytes > 0");
+    // The caller's slot may be the reference's (2*l for lz4, l-1 for lzf, :234-239); device slots use the bound.
+    j.d_stride = (bound + 15) & ~(size_t)15;
+    return CW_OK;
+}
+} // namespace
+
 int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, size_t block_bytes, size_t nblocks, void *digests,
                                 void *dst, size_t dst_stride, uint32_t *sizes)
 {
-    ThreadCtx &c = t_ctx;
-    int rc = c.open();
+    HostJob j;
+    int rc = host_job_init(j, hash_alg, comp_alg, src, block_bytes, nblocks, digests, dst != nullptr && sizes != nullptr);
     if (rc != CW_OK) return rc;
-    const bool do_hash = hash_alg != CW_HASH_NONE && digests != nullptr;
-    const bool do_comp = comp_alg != CW_COMP_NONE && dst != nullptr && sizes != nullptr;
-    if (nblocks == 0 || (!do_hash && !do_comp)) return CW_OK;
-    if (!src && block_bytes) return fail(CW_ERR_BAD_ARG, "NULL src");
-    if ((rc = check_block(block_bytes)) != CW_OK) return rc;
-    const size_t db = cw_digest_bytes(hash_alg);
-    if (do_hash && db == 0) return fail(CW_ERR_BAD_ARG, "unknown hash algorithm %d", hash_alg);
-    const size_t bound = do_comp ? cw_compress_bound(comp_alg, block_bytes) : 0;
-    if (do_comp && bound == 0) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
-    // The caller's slot may be the reference's (2*l for lz4, l-1 for lzf, :234-239); device slots use the bound.
-    const size_t d_stride = (bound + 15) & ~(size_t)15;
+    j.dst = (uint8_t *)dst; j.dst_stride = dst_stride; j.sizes = sizes;
+    return host_pipeline(j);
+}
 
-    const size_t per_block = block_bytes + (do_comp ? 2 * d_stride + 8 : 0) + 64; // input, slots, packed stream, digest/size/offset
-    size_t chunk = kMaxChunkBytes / (per_block ? per_block : 1);
-    if (chunk == 0) chunk = 1;
-    if (chunk > nblocks) chunk = nblocks;
+int cw_hash_and_compress_packed(int hash_alg, int comp_alg, const void *src, size_t block_bytes, size_t nblocks, void *digests,
+                                void *packed, size_t packed_cap, uint64_t *offsets, uint32_t *sizes)
+{
+    if (comp_alg != CW_COMP_LZ4 && comp_alg != CW_COMP_LZF) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
+    if (nblocks && (!packed || !offsets || !sizes)) return fail(CW_ERR_BAD_ARG, "NULL packed/offsets/sizes");
+    HostJob j;
+    int rc = host_job_init(j, hash_alg, comp_alg, src, block_bytes, nblocks, digests, true);
+    if (rc != CW_OK) return rc;
+    j.packed = (uint8_t *)packed; j.packed_cap = packed_cap; j.offsets = offsets; j.sizes = sizes;
+    return host_pipeline(j);
+}
 
-    if ((rc = c.src.reserve(chunk * block_bytes + 16)) != CW_OK) return rc;
-    if (do_hash && (rc = c.dig.reserve(chunk * db)) != CW_OK) return rc;
-    if (do_comp && ((rc = c.dst.reserve(chunk * d_stride)) != CW_OK || (rc = c.sizes.reserve(chunk * 4)) != CW_OK ||
-                    (rc = c.pack.reserve(chunk * d_stride)) != CW_OK || (rc = c.offs.reserve((chunk + 1) * 8)) != CW_OK))
-        return rc;
+// initializeGpu() (HashAndCompress.cpp:95-98) for the calling thread: its context on its device and everything the batch
+// path allocates on first use for batches of up to nblocks blocks, so that a timed run starts with warm buffers
+int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, int pinned_io)
+{
+    ThreadCtx *c;
+    int rc = thread_ctx(&c);
+    if (rc != CW_OK || nblocks == 0) return rc;
+    HostJob j;
+    int dummy = 0;
+    if ((rc = host_job_init(j, hash_alg, comp_alg, &dummy, block_bytes, nblocks, &dummy, true)) != CW_OK) return rc;
+    const size_t chunk = pipeline_chunk(block_bytes, nblocks);
+    for (Slot &s : c->slot)
+        if ((rc = slot_reserve(j, s, chunk, !pinned_io, !pinned_io)) != CW_OK) return rc;
+    return CW_OK;
+}
 
-    for (size_t first = 0; first < nblocks; first += chunk) {
-        const size_t n = nblocks - first < chunk ? nblocks - first : chunk;
-        const uint8_t *h_src = (const uint8_t *)src + first * block_bytes;
-        if (block_bytes) HIP_TRY(hipMemcpyAsync(c.src.p, h_src, n * block_bytes, hipMemcpyHostToDevice, c.stream));
-        if (do_comp) {
-            rc = dev_compress(comp_alg, (const uint8_t *)c.src.p, block_bytes, block_bytes, n, (uint8_t *)c.dst.p, d_stride,
-                              (uint32_t *)c.sizes.p, c.stream);
-            if (rc != CW_OK) return rc;
-        }
-        if (do_hash) {
-            rc = dev_hash(hash_alg, (const uint8_t *)c.src.p, block_bytes, block_bytes, n, (uint8_t *)c.dig.p, c.stream);
-            if (rc != CW_OK) return rc;
-            HIP_TRY(hipMemcpyAsync((uint8_t *)digests + first * db, c.dig.p, n * db, hipMemcpyDeviceToHost, c.stream));
-        }
-        if (do_comp) {
-            // the slots are packed into one stream on the device (pack_kernels.hip) so that the payload of the whole
-            // batch crosses the bus in one copy; the caller's slots (which may be smaller than the bound) are filled
-            // from the pinned staging buffer
-            hipError_t pe = cw::pack_launch((const uint8_t *)c.dst.p, d_stride, (const uint32_t *)c.sizes.p, n, (uint8_t *)c.pack.p,
-                                            (uint64_t *)c.offs.p, c.stream);
-            if (pe != hipSuccess) return fail(CW_ERR_HIP, "pack launch: %s", hipGetErrorString(pe));
-            HIP_TRY(hipMemcpyAsync(sizes + first, c.sizes.p, n * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_TRY(hipStreamSynchronize(c.stream));
-            size_t total = 0;
-            for (size_t i = 0; i < n; i++) {
-                const uint32_t sz = sizes[first + i];
-                if (sz > dst_stride) return fail(CW_ERR_BAD_ARG, "block %zu: %u bytes exceed dst_stride %zu", first + i, sz, dst_stride);
-                total += sz;
-            }
-            if (total) {
-                if ((rc = c.hpack.reserve(total)) != CW_OK) return rc;
-                HIP_TRY(hipMemcpyAsync(c.hpack.p, c.pack.p, total, hipMemcpyDeviceToHost, c.stream));
-                HIP_TRY(hipStreamSynchronize(c.stream));
-                const uint8_t *from = (const uint8_t *)c.hpack.p;
-                for (size_t i = 0; i < n; i++) {
-                    const uint32_t sz = sizes[first + i];
-                    memcpy((uint8_t *)dst + (first + i) * dst_stride, from, sz);
-                    from += sz;
-                }
-            }
-        }
-        HIP_TRY(hipStreamSynchronize(c.stream));
-    }
+// page-locked host memory for the batch path (hipHostMalloc / hipHostRegister): buffers the copy engines use in place
+void *cw_host_alloc(size_t bytes)
+{
+    if (ensure_init() != CW_OK) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { fail(CW_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+void cw_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int cw_host_register(void *p, size_t bytes)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return CW_OK;
+}
+int cw_host_unregister(void *p)
+{
+    HIP_TRY(hipHostUnregister(p));
     return CW_OK;
 }
 
 int cw_hash_tree_blocks(int hash_alg, const void *src, size_t block_bytes, size_t nblocks, unsigned leaf, unsigned node, unsigned max_level,
                         void *digests)
 {
-    ThreadCtx &c = t_ctx;
-    int rc = c.open();
+    ThreadCtx *cp;
+    int rc = thread_ctx(&cp);
     if (rc != CW_OK) return rc;
+    ThreadCtx &c = *cp;
     if (nblocks == 0) return CW_OK;
     if ((!src && block_bytes) || !digests) return fail(CW_ERR_BAD_ARG, "NULL pointer");
     if ((rc = check_block(block_bytes)) != CW_OK) return rc;
@@ -547,9 +875,10 @@ int cw_compress_blocks(int comp_alg, const void *src, size_t block_bytes, size_t
 int cw_decompress_blocks(int comp_alg, const void *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, void *dst,
                          size_t block_bytes, uint32_t *status)
 {
-    ThreadCtx &c = t_ctx;
-    int rc = c.open();
+    ThreadCtx *cp;
+    int rc = thread_ctx(&cp);
     if (rc != CW_OK) return rc;
+    ThreadCtx &c = *cp;
     if (nblocks == 0) return CW_OK;
     if (!comp || !sizes || !dst || !status) return fail(CW_ERR_BAD_ARG, "NULL pointer");
     if (comp_alg != CW_COMP_LZ4 && comp_alg != CW_COMP_LZF) return fail(CW_ERR_BAD_ARG, "unknown compression algorithm %d", comp_alg);
@@ -643,9 +972,22 @@ struct cw_offload {
     void (*on_complete)(void *) = nullptr;
     void *arg = nullptr;
     std::atomic<int> state{CW_OFFLOAD_INIT};
+    int error = CW_OK;      // why the object is in CW_OFFLOAD_FAILED
+    char error_msg[256] = "";
+    int device = -1;        // the device the object was created on
     hipStream_t stream = nullptr;
     DevBuf d_src, d_dig;
 };
+
+namespace {
+int offload_fail(cw_offload *h, int rc) // record the failure on the object, so that waiters and Complete() see it
+{
+    h->error = rc;
+    strncpy(h->error_msg, t_err, sizeof h->error_msg - 1);
+    h->state.store(CW_OFFLOAD_FAILED);
+    return rc;
+}
+} // namespace
 
 cw_offload_t *cw_offload_create(int hash_alg, int n_blocks, size_t block_bytes)
 {
@@ -656,7 +998,8 @@ cw_offload_t *cw_offload_create(int hash_alg, int n_blocks, size_t block_bytes)
     }
     cw_offload *h = new cw_offload;
     h->hash_alg = hash_alg; h->n_blocks = n_blocks; h->block_bytes = block_bytes;
-    if (hipSetDevice(g_device.load()) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+    h->device = current_device();
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         h->d_src.reserve((size_t)n_blocks * block_bytes + 16) != CW_OK || h->d_dig.reserve((size_t)n_blocks * cw_digest_bytes(hash_alg)) != CW_OK) {
         cw_offload_destroy(h);
         fail(CW_ERR_HIP, "cw_offload_create: device resources");
@@ -677,6 +1020,7 @@ int cw_offload_reset(cw_offload_t *h, char *data, char *results, void (*on_compl
 {
     if (!h) return fail(CW_ERR_BAD_ARG, "NULL offload");
     h->data = data; h->results = results; h->on_complete = on_complete; h->arg = arg;
+    h->error = CW_OK; h->error_msg[0] = 0;
     h->state.store(CW_OFFLOAD_INIT);
     return CW_OK;
 }
@@ -692,23 +1036,29 @@ int cw_offload_enqueue(cw_offload_t *h)
 int cw_offload_start(cw_offload_t *h)
 {
     if (!h) return fail(CW_ERR_BAD_ARG, "NULL offload");
-    int want = CW_OFFLOAD_QUEUED;
-    if (!h->state.compare_exchange_strong(want, CW_OFFLOAD_OFFLOADED)) return fail(CW_ERR_STATE, "Start: state %d != hQueued", want);
-    if (!h->data || !h->results) return fail(CW_ERR_BAD_ARG, "Start: Reset() gave no data/results");
+    if (h->state.load() != CW_OFFLOAD_QUEUED) return fail(CW_ERR_STATE, "Start: state %d != hQueued", h->state.load());
+    // everything that can fail is checked or attempted BEFORE the object counts as offloaded; a failure leaves it in
+    // CW_OFFLOAD_FAILED with the reason on the object (cw_offload_error), never in hOffloaded with nothing in flight
+    if (!h->data || !h->results) return offload_fail(h, fail(CW_ERR_BAD_ARG, "Start: Reset() gave no data/results"));
     const size_t bytes = (size_t)h->n_blocks * h->block_bytes, db = cw_digest_bytes(h->hash_alg);
-    HIP_TRY(hipSetDevice(g_device.load()));
-    if (bytes) HIP_TRY(hipMemcpyAsync(h->d_src.p, h->data, bytes, hipMemcpyHostToDevice, h->stream));
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(h->d_src.p, h->data, bytes, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return offload_fail(h, fail(CW_ERR_HIP, "Start: %s", hipGetErrorString(e)));
     int rc = dev_hash(h->hash_alg, (const uint8_t *)h->d_src.p, h->block_bytes, h->block_bytes, (size_t)h->n_blocks, (uint8_t *)h->d_dig.p, h->stream);
-    if (rc != CW_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(h->results, h->d_dig.p, (size_t)h->n_blocks * db, hipMemcpyDeviceToHost, h->stream));
+    if (rc != CW_OK) { (void)hipStreamSynchronize(h->stream); return offload_fail(h, rc); }
+    e = hipMemcpyAsync(h->results, h->d_dig.p, (size_t)h->n_blocks * db, hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(h->stream); return offload_fail(h, fail(CW_ERR_HIP, "Start: %s", hipGetErrorString(e))); }
+    h->state.store(CW_OFFLOAD_OFFLOADED);
     return CW_OK;
 }
 
 int cw_offload_complete(cw_offload_t *h)
 {
     if (!h) return fail(CW_ERR_BAD_ARG, "NULL offload");
+    if (h->state.load() == CW_OFFLOAD_FAILED) return fail(h->error, "Complete: the offload failed: %s", h->error_msg);
     if (h->state.load() != CW_OFFLOAD_OFFLOADED) return fail(CW_ERR_STATE, "Complete: state %d != hOffloaded", h->state.load());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return offload_fail(h, fail(CW_ERR_HIP, "Complete: %s", hipGetErrorString(e)));
     h->state.store(CW_OFFLOAD_COMPLETE);
     if (h->on_complete) h->on_complete(h->arg);
     return CW_OK;
@@ -716,6 +1066,7 @@ int cw_offload_complete(cw_offload_t *h)
 
 int cw_offload_completed(const cw_offload_t *h) { return h && h->state.load() == CW_OFFLOAD_COMPLETE; }
 int cw_offload_state(const cw_offload_t *h) { return h ? h->state.load() : CW_ERR_BAD_ARG; }
+int cw_offload_error(const cw_offload_t *h) { return h ? h->error : CW_ERR_BAD_ARG; }
 
 int cw_offload_do(cw_offload_t *h)
 {
@@ -744,7 +1095,13 @@ void offload_entry_point()
         cw_offload *h = q_work.front();
         q_work.pop_front();
         lk.unlock();
-        if (cw_offload_do(h) != CW_OK) fprintf(stderr, "libcwhc: offload failed: %s\n", t_err);
+        if (cw_offload_do(h) != CW_OK) {
+            // the reason is on the object (CW_OFFLOAD_FAILED, cw_offload_error); whoever waits for the callback is
+            // still woken, and finds Completed() false
+            fprintf(stderr, "libcwhc: offload failed: %s\n", t_err);
+            if (h->state.load() != CW_OFFLOAD_FAILED) offload_fail(h, CW_ERR_STATE);
+            if (h->on_complete) h->on_complete(h->arg);
+        }
         lk.lock();
     }
 }

@@ -12,7 +12,22 @@
 
 namespace cw {
 
+// Key of the per-(device, stream) scratch the launch sequences keep (the NULL stream exists once per device).  Every
+// entry also holds a launch mutex: a sequence of launches that shares scratch -- memset counters, scan, parse, redo; the
+// chained slices of one hash -- is queued under it, so that two host threads using the same stream cannot interleave
+// their sequences (stream order then keeps each sequence atomic).
+static inline uint64_t ws_key(hipStream_t s)
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return ((uint64_t)reinterpret_cast<uintptr_t>(s) << 4) | (uint64_t)(d & 15);
+}
+
 struct SkeinIV { uint64_t w[8]; };
+
+// The launch functions note which kernels they used, per calling thread (kind 0 = codec, 1 = hash): cw_profile_kernels
+// hands the names to the caller so that a benchmark reports what ran instead of guessing it from its arguments.
+void note_kernels(int kind, const char *names);
 
 // host: chaining value after the configuration block (Skein_*_Init)
 void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv, uint64_t tree_info = 0);
@@ -50,5 +65,7 @@ void pack_release_workspaces();
 hipError_t sum_sizes_launch(const uint32_t *sizes, size_t n, uint32_t raw_bytes, uint64_t *totals, hipStream_t stream);
 hipError_t gen_random_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
                              hipStream_t stream);
+hipError_t gen_mixed_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
+                            hipStream_t stream);
 
 } // namespace cw

@@ -5,7 +5,8 @@
 // reference-independent verifier of the compressors at full scale: encode -> decode -> compare on the device.
 // Format-level decoders (LZ4 block format; LZF stream format, src/compression_perf/include/lzf/lzf.h:83-95),
 // bounds-checked like the "safe" variants: a malformed or truncated input gives status 1, never an
-// out-of-bounds access.
+// out-of-bounds access -- a size that exceeds the slot (comp_stride) is malformed too, and every length is checked
+// against what is left before it is added, so no sum can wrap.
 //
 // A wavefront first copies its compressed block into LDS (coalesced; parsing token by token from global memory costs
 // a dependent ~1 us round trip per token), decodes it into a second LDS buffer (sequences are serial, their byte copies
@@ -38,8 +39,8 @@ __device__ __forceinline__ void copy_match(uint8_t *out, uint32_t op, uint32_t o
 }
 } // namespace
 
-// status[i]: 0 = ok and exactly block_bytes produced, 1 = malformed / wrong size.  sizes[i] == 0 (LZF "did not
-// fit") means the block was stored raw: it is copied through when raw_src is given, else flagged.
+// status[i]: 0 = ok and exactly block_bytes produced, 1 = malformed / wrong size (including sizes[i] == 0, LZF's "did not
+// fit": such a block was stored raw and there is nothing to decode) or a size larger than the slot.
 template <int ALG, bool STAGE_IN> // ALG: 0 = LZ4, 1 = LZF; STAGE_IN: compressed slot copied to LDS first
 __global__ void __launch_bounds__(64)
 decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const uint32_t *__restrict__ sizes, size_t nblocks,
@@ -52,7 +53,8 @@ decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const ui
         const uint8_t *gin = comp + blk * comp_stride;
         const uint32_t n = sizes[blk];
         uint32_t ip = 0, op = 0;
-        bool bad = n == 0 || (STAGE_IN && n > in_cap); // a valid slot never exceeds the codec's bound
+        // inside the slot; a valid slot never exceeds the codec's bound (~66 KB), and below 2^24 bytes no run of 255s can wrap a length
+        bool bad = n == 0 || n > comp_stride || n > (1u << 24) || (STAGE_IN && n > in_cap);
         __syncthreads();
         if (STAGE_IN && !bad) {
             if ((reinterpret_cast<uintptr_t>(gin) & 15) == 0) {
@@ -74,11 +76,11 @@ decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const ui
                     do { if (ip >= n) { bad = true; break; } c = bcast(in[ip]); ip++; lit += c; } while (c == 255);
                     if (bad) break;
                 }
-                if (ip + lit > n || op + lit > block_bytes) { bad = true; break; }
+                if (lit > n - ip || lit > block_bytes - op) { bad = true; break; } // ip <= n, op <= block_bytes: no wrap
                 for (uint32_t i = lane; i < lit; i += 64) out[op + i] = in[ip + i];
                 ip += lit; op += lit;
                 if (ip == n) break; // last sequence: literals only
-                if (ip + 2 > n) { bad = true; break; }
+                if (n - ip < 2) { bad = true; break; }
                 const uint32_t off = bcast((uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8)); ip += 2;
                 if (off == 0 || off > op) { bad = true; break; }
                 uint32_t ml = tok & 15;
@@ -87,8 +89,8 @@ decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const ui
                     do { if (ip >= n) { bad = true; break; } c = bcast(in[ip]); ip++; ml += c; } while (c == 255);
                     if (bad) break;
                 }
+                if (ml > block_bytes || ml + 4 > block_bytes - op) { bad = true; break; }
                 ml += 4;
-                if (op + ml > block_bytes) { bad = true; break; }
                 copy_match(out, op, off, ml, lane);
                 op += ml;
             }
@@ -97,7 +99,7 @@ decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const ui
                 const uint32_t ctrl = bcast(in[ip]); ip++;
                 if (ctrl < 32) {
                     const uint32_t run = ctrl + 1;
-                    if (ip + run > n || op + run > block_bytes) { bad = true; break; }
+                    if (run > n - ip || run > block_bytes - op) { bad = true; break; }
                     if (lane < run) out[op + lane] = in[ip + lane];
                     ip += run; op += run;
                 } else {
@@ -106,7 +108,7 @@ decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const ui
                     if (len == 7) { len += bcast(in[ip]); ip++; if (ip >= n) { bad = true; break; } }
                     const uint32_t off = (((ctrl & 0x1f) << 8) | bcast(in[ip])) + 1; ip++;
                     len += 2;
-                    if (off > op || op + len > block_bytes) { bad = true; break; }
+                    if (off > op || len > block_bytes - op) { bad = true; break; }
                     copy_match(out, op, off, len, lane);
                     op += len;
                 }

@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1021,16 +1022,367 @@ lz4_parse_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Parse kernel, third generation, for blocks that are read from global memory (> 4 KiB).
+//
+// What bounded the second generation at 64 KiB was its own speculation: every item of a batch fetched its candidate's
+// bytes, 16 arbitrary earlier positions = 16 cache lines per sequence, of which the parser needs 1.9 on text; 2,560
+// resident blocks have a 160 MiB working set, so those lines come over the fabric (about 4 TB/s of line fills at
+// 14 GB/s of input) and the load latency grows with every wavefront added (2 -> 10 wavefronts per CU: 4.7 -> 14.1 GB/s).
+// Here a 4-bit fingerprint of the inserted value (bits 15..18 of the multiplicative hash whose bits 19..31 are the
+// slot) sits beside every table slot, 4 KiB per block, and goes through the same one-instruction exchange as the
+// position: a candidate whose fingerprint differs cannot hold the same 4 bytes and is never fetched (15 of 16 are
+// not), candidates at positions 0..3 are compared against the block's first 8 bytes kept in registers.  20 KiB of LDS
+// per block = 8 blocks per CU instead of 10.
+// Also: the 16 bytes [p-4, p+12) around every item of a head batch and around every fetched candidate are ONE 16-byte
+// load each (before: 4 + 3 + 3 loads per sequence), and the winner's extension (forward <= 8, backward <= 3 bytes) is
+// scalar code on values read from its lane.
+// The fingerprint exchange relies on the same lane order as the position exchange; it is checked the same way: a
+// lane whose candidate was inserted by an earlier lane of the same batch must have received that lane's fingerprint.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kFpBytes = (1u << 13) / 2; // 4-bit fingerprint per table slot
+
+// Diagnostic build only (-DCW_STAMP, tools/parse_stamp.hip): where a sequence's cycles go.  A stamp is s_memtime behind a
+// drained LDS/scalar queue; the differences are summed per phase in scalar registers and added to g_stamp once per block.
+#ifdef CW_STAMP
+__device__ unsigned long long g_stamp[16];
+#define CW_STAMP_DECL uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_seq = 0; unsigned long long st_last = stamp_now();
+#define CW_STAMP_AT(i) do { const unsigned long long t_ = stamp_now(); st_acc[i] += (uint32_t)(t_ - st_last); st_last = t_; } while (0)
+#define CW_STAMP_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_stamp[i_], (unsigned long long)st_acc[i_]); atomicAdd(&g_stamp[15], (unsigned long long)st_seq); } } while (0)
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define CW_STAMP_DECL
+#define CW_STAMP_AT(i) do { } while (0)
+#define CW_STAMP_FLUSH() do { } while (0)
+#endif
+
+__device__ __forceinline__ uint32_t fp4(uint32_t v) { return ((v * 2654435761u) >> 15) & 0xFu; }
+__device__ __forceinline__ uint4 ld16g(const uint8_t *p)
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16); // unaligned global_load_dwordx4
+    return v;
+}
+
+// any batch of items (positions ascending with the lane): run_batch<false> + fingerprint upkeep.  Used for the first
+// search of a block and for searches that outlast their head batch; the loads are per field, as in the second generation.
+__device__ __forceinline__ BatchOut run_batch_fp(const uint8_t *in, uint16_t *tab, uint32_t tab_lds, uint32_t fp_lds, uint32_t pos, uint32_t v,
+                                                 bool active, bool tested, uint32_t anchor, uint32_t matchlimit, uint32_t lane)
+{
+    BatchOut r;
+    r.mpos = 0; r.match = 0; r.mc = 0; r.back = 0; r.stop = false; r.found = false; r.broken = false; r.flong = false; r.blong = false;
+    const uint32_t h = hash13(v), fp = fp4(v);
+    uint32_t old = 0, fo = 0;
+    if (active) old = lz::tab_fp_exchange(tab_lds, fp_lds, h, pos, fp, &fo);
+    if (__ballot(tested && old >= pos)) { r.broken = true; r.stop = true; return r; }
+    {   // fingerprint lane order: the lane that inserted `old` in this batch (positions ascend with the lane)
+        const uint32_t first = __builtin_amdgcn_readfirstlane(pos);
+        uint32_t j = 0;
+#pragma unroll
+        for (uint32_t s = 32; s; s >>= 1) {
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j + s) << 2), (int)pos);
+            if (pj <= old) j += s;
+        }
+        const uint32_t pfp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)fp);
+        // (old == 0 may also be an empty slot; position 0 is compared by its bytes, never by its fingerprint)
+        if (__ballot(tested && old >= first && old != 0 && pfp != fo)) { r.broken = true; r.stop = true; return r; }
+    }
+    const bool near_start = pos < 4 || old < 4;
+    Around ap, ac;
+    ap.before = 0; ap.at = 0; ap.after = 0; ac.before = 0; ac.at = 0; ac.after = 1;
+    if (tested) {
+        ac = around<false>(in, old, !near_start);
+        ap = around<false>(in, pos, !near_start);
+    }
+    const unsigned long long eqmask = __ballot(tested && ac.at == v);
+    if (!eqmask) return r;
+    const uint32_t w = (uint32_t)__builtin_ctzll(eqmask);
+    const uint32_t pm = __builtin_amdgcn_readlane(pos | (old << 16), w);
+    r.mpos = pm & 0xFFFFu; r.match = pm >> 16;
+    if (active && lane > w && old <= r.mpos) { tab[h] = (uint16_t)old; lz::fp_store(fp_lds, h, fo); }
+    const uint64_t x = ap.after ^ ac.after;
+    uint32_t nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+    const uint32_t lim = matchlimit - (pos + 4);
+    bool fl = false;
+    if (nf >= lim) nf = lim; else fl = nf == 8;
+    const uint32_t room = pos - anchor < old ? pos - anchor : old;
+    const uint32_t y = ap.before ^ ac.before;
+    uint32_t nb = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+    bool bl = false;
+    if (near_start) { nb = 0; bl = room != 0; }
+    else if (nb >= room) nb = room;
+    else bl = nb == 4;
+    const uint32_t packed = __builtin_amdgcn_readlane(nf | (nb << 8) | ((uint32_t)fl << 16) | ((uint32_t)bl << 17), w);
+    r.mc = packed & 0xFFu; r.back = (packed >> 8) & 0xFFu;
+    r.flong = (packed >> 16) & 1u; r.blong = (packed >> 17) & 1u;
+    r.found = true; r.stop = true;
+    return r;
+}
+
+// Head batch of a search after a match, on the register window W: lane t holds the 4 bytes at base + t, base = mend - 2.
+// Lane 0 inserts mend-2, lane 1 idles, lane 2 re-tests mend, lane t >= 3 probes mend + t - 2: items in lane order.
+// The window makes the batch independent of memory: the only load is the fetch of candidates whose fingerprint agrees.
+#ifdef CW_STAMP
+#define CW_HEAD_STAMP_PARAMS , uint32_t (&st_acc)[8], unsigned long long &st_last
+#define CW_HEAD_STAMP_ARGS , st_acc, st_last
+#else
+#define CW_HEAD_STAMP_PARAMS
+#define CW_HEAD_STAMP_ARGS
+#endif
+template <uint32_t HEADW>
+__device__ __forceinline__ BatchOut head_batch_fp(const uint8_t *g, uint16_t *tab, uint32_t tab_lds, uint32_t fp_lds, uint32_t W, uint32_t base,
+                                                  uint32_t mflimit, uint32_t matchlimit, uint32_t first_lo, uint32_t first_hi, uint32_t lane
+                                                  CW_HEAD_STAMP_PARAMS)
+{
+    constexpr unsigned long long kHeadMask = (HEADW >= 64 ? ~0ull : (1ull << (HEADW & 63)) - 1) & ~2ull;
+    BatchOut r;
+    r.mpos = 0; r.match = 0; r.mc = 0; r.back = 0; r.stop = false; r.found = false; r.broken = false; r.flong = false; r.blong = false;
+    const uint32_t pos = base + lane, anchor = base + 2;
+    const unsigned long long lmask = __ballot(pos <= mflimit);
+    const bool active = ((lmask & kHeadMask) >> lane) & 1u, tested = active && lane != 0;
+    const uint32_t hp = W * 2654435761u, h = hp >> 19, fp = (hp >> 15) & 0xFu;
+    uint32_t old = 0, fo = 0;
+    CW_STAMP_AT(1); // window ready (bpermute or reload landed), hash computed
+    if (active) old = lz::tab_fp_exchange(tab_lds, fp_lds, h, pos, fp, &fo);
+    CW_STAMP_AT(2); // exchange
+    // candidates: positions 0..3 from the block's first 8 bytes, the others only if the fingerprint agrees
+    const bool need = tested && old >= 4 && fo == fp;
+    uint4 cd = make_uint4(0, 0, 0, 0);
+    if (need) cd = ld16g(g + old - 4);
+    // lane order of the two exchanges (checked while the candidates are on their way): a candidate that an earlier lane of
+    // this batch inserted sits at base + its lane, and must have come with that lane's fingerprint
+    const uint32_t pfp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((old - base) << 2), (int)fp);
+    if (__ballot(tested && (old >= pos || (old >= base && pfp != fo)))) { r.broken = true; r.stop = true; return r; }
+    const uint32_t c_small = __builtin_amdgcn_alignbyte(first_hi, first_lo, old & 3u);
+    const bool eq = tested && (old < 4 ? c_small == W : need && cd.y == W);
+    const unsigned long long eqmask = __ballot(eq);
+    CW_STAMP_AT(3); // candidate fetch + lane-order check
+    if (!eqmask) {
+        r.stop = (~lmask & kHeadMask) != 0; // the next probe would pass the end of the block
+        return r;
+    }
+    const uint32_t w = (uint32_t)__builtin_ctzll(eqmask);
+    r.mpos = base + w;
+    r.match = (uint32_t)__builtin_amdgcn_readlane(old, w);
+    if (active && lane > w && old <= r.mpos) { tab[h] = (uint16_t)old; lz::fp_store(fp_lds, h, fo); }
+    // the winner's extension, scalar: forward bytes 4..11 are the window 4 and 8 lanes up, the bytes before it 4 lanes down
+    const uint32_t room = w - 2 < r.match ? w - 2 : r.match; // mpos - anchor = w - 2
+    if (r.match >= 4) {
+        const uint64_t pa = (uint32_t)__builtin_amdgcn_readlane(W, w + 4) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(W, w + 8) << 32);
+        const uint64_t ca = (uint32_t)__builtin_amdgcn_readlane(cd.z, w) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(cd.w, w) << 32);
+        const uint64_t x = pa ^ ca;
+        uint32_t nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        const uint32_t lim = matchlimit - (r.mpos + 4);
+        if (nf >= lim) nf = lim; else r.flong = nf == 8;
+        // bytes [mpos-4, mpos): for w >= 6 a window lane; below that only the bytes from the anchor (lane 2) on can count,
+        // and they are the low bytes of lane 2's value moved to the top (room < 4 cuts the rest off)
+        const uint32_t pb = w >= 6 ? (uint32_t)__builtin_amdgcn_readlane(W, w - 4) : (uint32_t)__builtin_amdgcn_readlane(W, 2) << (8 * ((6 - w) & 3));
+        const uint32_t y = pb ^ (uint32_t)__builtin_amdgcn_readlane(cd.x, w);
+        uint32_t nb = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+        if (nb >= room) nb = room; else r.blong = nb == 4;
+        r.mc = nf; r.back = nb;
+        (void)anchor;
+    } else { // candidate in the first 4 bytes: both directions in the byte loops
+        r.flong = true; r.blong = room != 0;
+    }
+    r.found = true; r.stop = true;
+    CW_STAMP_AT(4); // undo + scalar extension
+    return r;
+}
+
+template <uint32_t HEADW>
+__global__ void __launch_bounds__(64)
+lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
+                    uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes,
+                    const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t *__restrict__ requeue,
+                    uint32_t force_redo)
+{
+    constexpr unsigned long long kHeadMask = HEADW >= 64 ? ~0ull : (1ull << (HEADW & 63)) - 1;
+    constexpr uint32_t kWinNeed = HEADW + 8; // lanes a head batch may read: its items and the 8 bytes after the last of them
+    static_assert(kWinNeed <= 64, "the window is one register: a head batch and its look-ahead must fit 64 lanes");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(tab), fp_lds = tab_lds + kTabBytes;
+    const uint32_t lane = threadIdx.x;
+
+    const uint32_t qcount = counters[1];
+    volatile uint32_t *mailbox = reinterpret_cast<volatile uint32_t *>(tab);
+    for (uint32_t guard = 0; guard <= qcount; guard++) {
+        __syncthreads();
+        if (lane == 0) *mailbox = atomicAdd(&counters[0], 1u);
+        __syncthreads();
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(*mailbox);
+        if (qi >= qcount) break;
+        const size_t blk = queue[qi];
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+
+        __syncthreads();
+        for (uint32_t i = lane; i < (kTabBytes + kFpBytes) / 16; i += 64) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+
+        uint32_t anchor = 0, op = 0;
+        bool broken = force_redo != 0;
+
+        if (!broken && n >= kMFLimit + 1) {
+            const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
+            const uint32_t first_lo = __builtin_amdgcn_readfirstlane(rd32(g, 0)), first_hi = __builtin_amdgcn_readfirstlane(rd32(g, 4));
+            // The window: lane t holds the 4 bytes at wbase + t for t < wvalid.  A match moves it up by mend - wbase - 2 lanes
+            // (one ds_bpermute); when fewer than kWinNeed lanes would stay valid it is reloaded (a 64-lane gather of 68 bytes).
+            CW_STAMP_DECL
+            uint32_t W, Wlit, wbase = 0, wvalid = 0, s0 = 1;
+            uint32_t gen_t0 = HEADW; // first item of a search that its head batch did not cover (the first search has one probe more)
+            bool head_found; // the match came out of the head batch: its literals are window bytes
+            uint32_t lit_lane;  // window lane of the literal run's first byte
+            BatchOut bo;
+            {   // first search of the block: lane 0 inserts position 0, lane 1 idles, lane t probes t-1
+                const uint32_t pos = lane == 0 ? 0u : lane - 1;
+                const unsigned long long lmask = __ballot(pos <= mflimit);
+                const bool active = ((lmask & ~2ull & kHeadMask) >> lane) & 1u;
+                W = rd32(g, pos <= mflimit ? pos : 0u);
+                bo = run_batch_fp(g, tab, tab_lds, fp_lds, pos, W, active, active && lane != 0, anchor, matchlimit, lane);
+                if (!bo.stop && (~lmask & kHeadMask)) bo.stop = true;
+                head_found = bo.found; lit_lane = 1;
+            }
+            for (uint32_t seq = 0; seq < n; seq++) {
+                if (!bo.stop) { // rare: more than HEADW - 2 probes without a match
+                    head_found = false;
+                    for (uint32_t t0 = gen_t0;; t0 += 64) {
+                        const uint32_t k = t0 + lane - 2;
+                        const uint32_t dk = probe_delta(k), stepk = (63u + k) >> 6;
+                        const uint32_t p2 = s0 + dk;
+                        const bool act2 = p2 + stepk <= mflimit + 1;
+                        if (!__ballot(act2)) break;
+                        const uint32_t v2 = rd32(g, act2 ? p2 : 0u);
+                        bo = run_batch_fp(g, tab, tab_lds, fp_lds, p2, v2, act2, act2, anchor, matchlimit, lane);
+                        if (bo.stop || __ballot(!act2)) break;
+                    }
+                }
+                CW_STAMP_AT(5); // searches that outlast their head batch
+                if (bo.broken) { broken = true; break; }
+                if (!bo.found) break;
+                uint32_t mpos = bo.mpos, match = bo.match, mc = bo.mc, back = bo.back;
+#ifdef CW_STAMP
+                st_seq++;
+#endif
+
+                if (bo.flong) { // long match: keep counting, 64 bytes per round
+                    for (;;) {
+                        const uint32_t i = mpos + kMinMatch + mc + lane;
+                        const bool ok = i < matchlimit && g[i] == g[match + kMinMatch + mc + lane];
+                        const uint32_t cnt = ctz64(~__ballot(ok));
+                        mc += cnt;
+                        if (cnt < 64) break;
+                    }
+                }
+                if (bo.blong) { // long catch-up (rare)
+                    for (;;) {
+                        const uint32_t j = back + lane + 1;
+                        const bool ok = mpos >= anchor + j && match >= j && g[mpos - j] == g[match - j];
+                        const uint32_t cnt = ctz64(~__ballot(ok));
+                        back += cnt;
+                        if (cnt < 64) break;
+                    }
+                }
+                const uint32_t mend = mpos + kMinMatch + mc; // first byte after the match
+                const uint32_t ip = mpos - back;
+                match -= back; mc += back;
+                if (ip < anchor || mend > n) { broken = true; break; } // cannot happen; never write out of bounds
+
+                CW_STAMP_AT(6); // byte loops of long matches / catch-ups
+                // ---- the next head batch's window first (its exchange of lanes overlaps the stores below): move it to mend - 2,
+                //      or reload it; the literals of this sequence are bytes of the window as it stands ----
+                const bool more = mend <= mflimit;
+                Wlit = W;
+                if (more) {
+                    const uint32_t nbase = mend - 2, shift = nbase - wbase;
+                    if (shift + kWinNeed <= wvalid) {
+                        W = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + shift) << 2), (int)W);
+                        wvalid -= shift;
+                    } else {
+                        const uint32_t p = nbase + lane;
+                        W = rd32(g, p <= n - 4 ? p : n - 4);
+                        wvalid = 64;
+                    }
+                    wbase = nbase;
+                }
+
+                // ---- emit: literals [anchor, ip), offset, match length ----
+                const uint32_t lit = ip - anchor, tok_pos = op;
+                uint32_t token;
+                op += 1;
+                if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
+                else token = lit << 4;
+                if (head_found) { // at most HEADW - 3 literals, all of them window bytes
+                    if (lane - lit_lane < lit) out[op + lane - lit_lane] = (uint8_t)Wlit;
+                } else {
+                    copy_out(out + op, g, anchor, lit, lane);
+                }
+                op += lit;
+                const uint32_t off = ip - match, off_pos = op;
+                op += 2;
+                if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
+                else token += mc;
+                if (lane < 3) {
+                    const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
+                    const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
+                    out[where] = (uint8_t)what;
+                }
+
+                anchor = mend;
+                CW_STAMP_AT(7); // window move issued, sequence emitted
+                if (!more) break; // end of parse: remaining bytes are literals
+                s0 = mend + 1; gen_t0 = HEADW - 1;
+                bo = head_batch_fp<HEADW>(g, tab, tab_lds, fp_lds, W, wbase, mflimit, matchlimit, first_lo, first_hi, lane CW_HEAD_STAMP_ARGS);
+                head_found = true; lit_lane = 2;
+            }
+            CW_STAMP_FLUSH();
+        }
+        if (broken) {
+            if (lane == 0) requeue[atomicAdd(&counters[5], 1u)] = (uint32_t)blk;
+            continue;
+        }
+
+        // ---- last literals ----
+        {
+            const uint32_t run = n - anchor;
+            const uint32_t tok_pos = op;
+            op += 1;
+            if (run >= 15) {
+                if (lane == 0) out[tok_pos] = 15u << 4;
+                op += put_len(out + op, run - 15, lane);
+            } else if (lane == 0) {
+                out[tok_pos] = (uint8_t)(run << 4);
+            }
+            copy_out(out + op, g, anchor, run, lane);
+            op += run;
+        }
+        if (lane == 0) sizes[blk] = op;
+    }
+}
+
 // per-stream workspace: counters[8] (parse queue head, tail; scan feed; -; second queue head, tail) + two queues
 namespace {
-struct Workspace { uint32_t *p = nullptr; size_t cap = 0; };
+struct Workspace { uint32_t *p = nullptr; size_t cap = 0; std::mutex launch; };
 std::mutex ws_lock;
-std::unordered_map<hipStream_t, Workspace> ws_map;
+std::unordered_map<uint64_t, Workspace> ws_map; // references stay valid across inserts
 
-hipError_t get_workspace(hipStream_t stream, size_t nblocks, uint32_t **out, size_t *cap_out)
+Workspace &find_workspace(hipStream_t stream)
 {
     std::lock_guard<std::mutex> g(ws_lock);
-    Workspace &w = ws_map[stream];
+    return ws_map[ws_key(stream)];
+}
+
+// caller holds w.launch
+hipError_t grow_workspace(Workspace &w, size_t nblocks, uint32_t **out, size_t *cap_out)
+{
     if (w.cap < nblocks) { // only ever on the first (or a larger) call on this stream
         if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
         w.p = nullptr; w.cap = 0;
@@ -1063,7 +1415,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const uint32_t stage_max = sm_env && atoi(sm_env) >= 0 ? (uint32_t)atoi(sm_env) : 4096u;
     const bool staged = n <= (stage_max < kStageMax ? stage_max : kStageMax);
     // staged bytes are read as aligned dwords: a size that is not a multiple of 4 gets 16 bytes of slack behind it
-    const uint32_t lds = kTabBytes + (staged ? ((n + 15u) & ~15u) + (n % 4 ? 16u : 0u) : 0u);
+    uint32_t lds = kTabBytes + (staged ? ((n + 15u) & ~15u) + (n % 4 ? 16u : 0u) : 0u);
     static bool attr_set = false; // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lz4_blocks_kernel<true>),
@@ -1076,7 +1428,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     uint32_t *ws = nullptr;
     size_t cap = 0;
-    hipError_t e = get_workspace(stream, nblocks, &ws, &cap);
+    Workspace &wsp = find_workspace(stream);
+    std::lock_guard<std::mutex> sequence(wsp.launch); // counters/queues are shared by every launch below
+    hipError_t e = grow_workspace(wsp, nblocks, &ws, &cap);
     if (e != hipSuccess) return e;
     uint32_t *counters = ws, *queue = ws + 8, *queue2 = ws + 8 + cap;
 
@@ -1113,10 +1467,23 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                            dst_stride, sizes, scan_probes(n), queue, counters);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (mode && strcmp(mode, "scan") == 0) return hipSuccess;
+    const bool span = streamable && n >= kChunk && (n & (n - 1)) == 0 && !(mode && strcmp(mode, "stream") == 0) && nblocks >= (65536u / n ? 65536u / n : 1u);
+    const char *scan_name = !streamable ? "cw::lz4_scan_kernel" : span ? "cw::lz4_scan_span_kernel" : "cw::lz4_scan_stream_kernel";
+    if (mode && strcmp(mode, "scan") == 0) { note_kernels(0, scan_name); return hipSuccess; }
     // parse: queued blocks only; LDS admits 160 KiB / lds workgroups per CU
+    // CW_LZ4_PARSE=fp: blocks read from global memory go through the fingerprint parser (20 KiB of LDS, 8 blocks per CU).
+    // Measured on text at 64 KiB: 11.9 GB/s against 14.2 GB/s for the second generation with its 10 blocks per CU -- both
+    // are bound by the instruction latency of one sequence's serial chain (tools/parse_stamp.hip), not by candidate
+    // traffic, so the extra blocks win; the second generation stays the default.
+    static const char *gen_env = getenv("CW_LZ4_PARSE");
+    const bool use_fp = !staged && gen_env && strcmp(gen_env, "fp") == 0;
+    static const char *hw_env = getenv("CW_LZ4_HEADW"); // head batch width of the fingerprint parser (profiling knob: 8, 16, 32)
+    const int headw = hw_env ? atoi(hw_env) : 16;
+    if (use_fp) lds = kTabBytes + kFpBytes;
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
-    const size_t want = 256 * (per_cu > 10 ? 10 : per_cu);
+    static const char *pwpc_env = getenv("CW_PARSE_WPC"); // parse wavefronts per CU (profiling knob; default: all the LDS admits)
+    const size_t pwpc = pwpc_env && atoi(pwpc_env) > 0 ? (size_t)atoi(pwpc_env) : 10;
+    const size_t want = 256 * (per_cu > pwpc ? pwpc : per_cu);
     const size_t grid = nblocks < want ? nblocks : want;
     // CW_LZ4_MODE=cut parses with the first-generation (write/read-back) kernel only (profiling knob)
     const bool cut_only = mode && strcmp(mode, "cut") == 0;
@@ -1127,10 +1494,26 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if (staged)
             hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                                dst_stride, sizes, queue, counters, queue2, force_redo);
+        else if (use_fp && headw == 32)
+            hipLaunchKernelGGL(lz4_parse_fp_kernel<32>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, queue, counters, queue2, force_redo);
+        else if (use_fp && headw == 8)
+            hipLaunchKernelGGL(lz4_parse_fp_kernel<8>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, queue, counters, queue2, force_redo);
+        else if (use_fp)
+            hipLaunchKernelGGL(lz4_parse_fp_kernel<16>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
+                               dst_stride, sizes, queue, counters, queue2, force_redo);
         else
             hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                                dst_stride, sizes, queue, counters, queue2, force_redo);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    {
+        static thread_local char names[160];
+        snprintf(names, sizeof names, "%s + %s", scan_name,
+                 cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
+                 : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");
+        note_kernels(0, names);
     }
     // blocks the exchange-based parser handed back (none, unless the LDS ever applies lanes out of order)
     const uint32_t *q = cut_only ? queue : queue2;

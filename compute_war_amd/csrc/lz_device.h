@@ -39,6 +39,29 @@ __device__ __forceinline__ uint32_t tab_exchange(uint32_t tab_lds, uint32_t h, u
     return (old >> sh) & 0xFFFFu;
 }
 
+// Table exchange + fingerprint exchange of one batch of items: the 16-bit slot h of the position table (byte address
+// tab_lds) and the 4-bit slot h of the fingerprint table beside it (byte address fp_lds, eight slots per 32-bit word),
+// two ds_mskor_rtn_b32 behind one wait.  Returns the previous position; *fp_old receives the previous fingerprint.
+__device__ __forceinline__ uint32_t tab_fp_exchange(uint32_t tab_lds, uint32_t fp_lds, uint32_t h, uint32_t pos, uint32_t fp,
+                                                    uint32_t *fp_old)
+{
+    const uint32_t addr = tab_lds + (h >> 1) * 4, sh = (h & 1) * 16;
+    const uint32_t faddr = fp_lds + (h >> 3) * 4, fsh = (h & 7) * 4;
+    uint32_t old, fo;
+    asm volatile("ds_mskor_rtn_b32 %0, %2, %3, %4\n\tds_mskor_rtn_b32 %1, %5, %6, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old), "=&v"(fo)
+                 : "v"(addr), "v"(0xFFFFu << sh), "v"(pos << sh), "v"(faddr), "v"(0xFu << fsh), "v"(fp << fsh)
+                 : "memory");
+    *fp_old = (fo >> fsh) & 0xFu;
+    return (old >> sh) & 0xFFFFu;
+}
+// put a fingerprint back (undo of a speculative exchange); no value returned, ordered with the wavefront's other LDS operations
+__device__ __forceinline__ void fp_store(uint32_t fp_lds, uint32_t h, uint32_t fp)
+{
+    const uint32_t faddr = fp_lds + (h >> 3) * 4, fsh = (h & 7) * 4;
+    asm volatile("ds_mskor_b32 %0, %1, %2" : : "v"(faddr), "v"(0xFu << fsh), "v"(fp << fsh) : "memory");
+}
+
 // the 16 bytes around a position: [p-4, p) (only if has_before), [p, p+4), [p+4, p+12)
 struct Around { uint32_t before, at; uint64_t after; };
 template <bool STAGED>

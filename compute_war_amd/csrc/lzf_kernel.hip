@@ -707,16 +707,17 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
 namespace {
 struct LinkSpace { uint16_t *p = nullptr; size_t cap = 0; uint32_t *counter = nullptr; };
+struct LinkEntry { LinkSpace s; std::mutex launch; };
 std::mutex link_lock;
-std::unordered_map<hipStream_t, LinkSpace> link_map;
+std::unordered_map<uint64_t, LinkEntry> link_map; // references stay valid across inserts
 }
 
 void lzf_release_workspaces()
 {
     std::lock_guard<std::mutex> g(link_lock);
     for (auto &kv : link_map) {
-        if (kv.second.p) (void)hipFree(kv.second.p);
-        if (kv.second.counter) (void)hipFree(kv.second.counter);
+        if (kv.second.s.p) (void)hipFree(kv.second.s.p);
+        if (kv.second.s.counter) (void)hipFree(kv.second.s.counter);
     }
     link_map.clear();
 }
@@ -757,9 +758,14 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const size_t chunk_max = ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
         LinkSpace ls;
+        LinkEntry *entry;
         {
             std::lock_guard<std::mutex> g(link_lock);
-            LinkSpace &w = link_map[stream];
+            entry = &link_map[ws_key(stream)];
+        }
+        std::lock_guard<std::mutex> sequence(entry->launch); // the link array and the counter are shared by the launches below
+        {
+            LinkSpace &w = entry->s;
             if (w.cap < chunk * n2) {
                 if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
                 w.p = nullptr; w.cap = 0;
@@ -804,6 +810,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         }
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, in_lds, 1u);
+        note_kernels(0, big ? "cw::lzf_links_kernel + cw::lzf_chain_kernel<true>" : "cw::lzf_links_kernel + cw::lzf_chain_kernel<false>");
         return hipGetLastError();
     }
     if (!cut_only) {
@@ -818,6 +825,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                        dst_stride, sizes, in_lds, cut_only ? 0u : 1u);
+    note_kernels(0, cut_only ? "cw::lzf_blocks_kernel" : in_lds ? "cw::lzf_parse_kernel<true>" : "cw::lzf_parse_kernel<false>");
     return hipGetLastError();
 }
 

@@ -35,6 +35,52 @@ gen_random_kernel(uint64_t seed, uint64_t first_block, size_t total_pairs, unsig
     }
 }
 
+// gen_mixed: the compressible synthetic mix of SURVEY.md 8(d) -- even blocks are the uniform-random stream above, odd
+// blocks repeat a 64-byte motif (8 u64 words keyed by the block) in which every byte is replaced by a random one with
+// probability 1/16, so that the LZ4/LZF match + literal emit loops run (short matches broken by literals, offsets of a
+// few motif periods).  Word w of odd block b:
+//   motif  m = splitmix64(seed ^ kSaltMotif ^ (b << 13 | (w & 7)))
+//   draw   r = splitmix64(seed ^ kSaltMutate ^ (b << 13 | w)),  r2 = splitmix64(r)
+//   byte k = nibble k of r is 0 ? byte k of r2 : byte k of m
+// The checker regenerates sampled blocks on the host from this definition (the test infrastructure holds its own twin).
+constexpr uint64_t kSaltMotif = 0x6D6F746966ULL, kSaltMutate = 0x6D7574617465ULL;
+
+static __device__ __forceinline__ uint64_t mixed_word(uint64_t seed, uint64_t blk, uint64_t w)
+{
+    if ((blk & 1) == 0) return splitmix64(seed ^ ((blk << 13) | w));
+    const uint64_t m = splitmix64(seed ^ kSaltMotif ^ ((blk << 13) | (w & 7)));
+    const uint64_t r = splitmix64(seed ^ kSaltMutate ^ ((blk << 13) | w)), r2 = splitmix64(r);
+    uint64_t mask = 0; // 0xFF in every byte whose nibble of r is zero
+#pragma unroll
+    for (int k = 0; k < 8; k++) mask |= ((r >> (4 * k)) & 15) == 0 ? 0xFFULL << (8 * k) : 0;
+    return (m & ~mask) | (r2 & mask);
+}
+
+__global__ void __launch_bounds__(256)
+gen_mixed_kernel(uint64_t seed, uint64_t first_block, size_t total_pairs, unsigned pairs_per_block, uint4 *__restrict__ dst)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pairs; i += stride) {
+        const uint64_t blk = first_block + i / pairs_per_block;
+        const uint64_t w = 2 * (i % pairs_per_block);
+        const uint64_t a = mixed_word(seed, blk, w), b = mixed_word(seed, blk, w + 1);
+        dst[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    }
+}
+
+hipError_t gen_mixed_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
+                            hipStream_t stream)
+{
+    if (nblocks == 0 || block_bytes == 0) return hipSuccess;
+    if (block_bytes % 16 || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
+    const size_t total = nblocks * (block_bytes / 16);
+    size_t grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(gen_mixed_kernel, dim3((unsigned)grid), dim3(256), 0, stream, seed, first_block, total,
+                       (unsigned)(block_bytes / 16), reinterpret_cast<uint4 *>(dst));
+    return hipGetLastError();
+}
+
 hipError_t gen_random_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
                              hipStream_t stream)
 {

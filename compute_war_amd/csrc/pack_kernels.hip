@@ -108,9 +108,9 @@ pack_copy_kernel(const uint8_t *__restrict__ slots, size_t slot_stride, const ui
     }
 }
 
-struct Workspace { unsigned long long *p = nullptr; size_t cap = 0; };
+struct Workspace { unsigned long long *p = nullptr; size_t cap = 0; std::mutex launch; };
 std::mutex ws_lock;
-std::unordered_map<hipStream_t, Workspace> ws_map;
+std::unordered_map<uint64_t, Workspace> ws_map; // references stay valid across inserts
 
 } // namespace
 
@@ -127,9 +127,14 @@ hipError_t pack_launch(const uint8_t *slots, size_t slot_stride, const uint32_t 
     if (nblocks == 0) return hipMemsetAsync(offsets, 0, sizeof(uint64_t), stream);
     const size_t ntiles = (nblocks + kTile - 1) / kTile;
     unsigned long long *partial = nullptr;
+    Workspace *wsp;
     {
         std::lock_guard<std::mutex> g(ws_lock);
-        Workspace &w = ws_map[stream];
+        wsp = &ws_map[ws_key(stream)];
+    }
+    std::lock_guard<std::mutex> sequence(wsp->launch); // the tile partials are shared by the launches below
+    {
+        Workspace &w = *wsp;
         if (w.cap < ntiles) { // first (or a larger) call on this stream
             if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
             w.p = nullptr; w.cap = 0;

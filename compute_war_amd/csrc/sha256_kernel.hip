@@ -150,16 +150,21 @@ sha256_blocks_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t
         }
     }
 
-    uint4 *out = reinterpret_cast<uint4 *>(digests + gid * 32);
-    out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
-    out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+    uint8_t *o = digests + gid * 32;
+    if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+        uint4 *out = reinterpret_cast<uint4 *>(o);
+        out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+        out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+    } else { // any alignment: big-endian bytes
+#pragma unroll
+        for (int k = 0; k < 32; k++) o[k] = (uint8_t)(h[k >> 2] >> (24 - 8 * (k & 3)));
+    }
 }
 
 hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *digests,
                          hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
-    if (reinterpret_cast<uintptr_t>(digests) & 15) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((nblocks + CW_SKEIN_THREADS - 1) / CW_SKEIN_THREADS)), block(CW_SKEIN_THREADS);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
     const bool ragged = (block_bytes % 64) != 0;
@@ -168,6 +173,8 @@ hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stri
     else if (aligned) CW_LAUNCH(true, true);
     else if (!ragged) CW_LAUNCH(false, false);
     else CW_LAUNCH(false, true);
+    note_kernels(1, aligned ? (ragged ? "cw::sha256_blocks_kernel<true, true>" : "cw::sha256_blocks_kernel<true, false>")
+                            : (ragged ? "cw::sha256_blocks_kernel<false, true>" : "cw::sha256_blocks_kernel<false, false>"));
 #undef CW_LAUNCH
     return hipGetLastError();
 }

@@ -267,7 +267,7 @@ skein_blocks_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t 
     }
 
     uint8_t *out = digests + gid * digest_bytes;
-    if ((digest_bytes & 15) == 0) {
+    if (((digest_bytes | (unsigned)reinterpret_cast<uintptr_t>(out)) & 15) == 0) { // else: any alignment, byte stores
         uint4 *o4 = reinterpret_cast<uint4 *>(out);
 #pragma unroll
         for (int k = 0; k < NW / 2; k++)
@@ -357,7 +357,7 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
     }
 
     uint8_t *out = digests + gid * digest_bytes;
-    if ((digest_bytes & 15) == 0) {
+    if (((digest_bytes | (unsigned)reinterpret_cast<uintptr_t>(out)) & 15) == 0) { // else: any alignment, byte stores
         uint4 *o4 = reinterpret_cast<uint4 *>(out);
 #pragma unroll
         for (int k = 0; k < NW / 2; k++)
@@ -452,7 +452,7 @@ skein_slice_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
         return;
     }
     uint8_t *out = digests + gid * digest_bytes;
-    if ((digest_bytes & 15) == 0) {
+    if (((digest_bytes | (unsigned)reinterpret_cast<uintptr_t>(out)) & 15) == 0) { // else: any alignment, byte stores
         uint4 *o4 = reinterpret_cast<uint4 *>(out);
 #pragma unroll
         for (int k = 0; k < NW / 2; k++)
@@ -464,9 +464,9 @@ skein_slice_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 }
 
 namespace {
-struct SliceSpace { uint64_t *p = nullptr; size_t cap = 0; };
+struct SliceSpace { uint64_t *p = nullptr; size_t cap = 0; std::mutex launch; };
 std::mutex slice_lock;
-std::unordered_map<hipStream_t, SliceSpace> slice_map;
+std::unordered_map<uint64_t, SliceSpace> slice_map; // references stay valid across inserts
 }
 
 void skein_release_workspaces()
@@ -492,9 +492,14 @@ hipError_t skein_sliced_launch(int nw, const uint8_t *src, size_t block_bytes, s
     size_t slice_steps = (total + nsl - 1) / nsl;
     slice_steps = (slice_steps + spl - 1) / spl * spl;
     uint64_t *state = nullptr;
+    SliceSpace *wsp;
     {
         std::lock_guard<std::mutex> g(slice_lock);
-        SliceSpace &w = slice_map[stream];
+        wsp = &slice_map[ws_key(stream)];
+    }
+    std::lock_guard<std::mutex> sequence(wsp->launch); // the slices hand their chaining values on through w.p
+    {
+        SliceSpace &w = *wsp;
         if (w.cap < nblocks * (size_t)nw) {
             if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
             w.p = nullptr; w.cap = 0;
@@ -514,6 +519,7 @@ hipError_t skein_sliced_launch(int nw, const uint8_t *src, size_t block_bytes, s
             hipLaunchKernelGGL((skein_slice_kernel<4, true>), grid, block, 0, stream, src, block_bytes, src_stride, nblocks, iv, digests,
                                digest_bytes, state, b, e);
     }
+    note_kernels(1, nw == 8 ? "cw::skein_slice_kernel<8, true>" : "cw::skein_slice_kernel<4, true>");
     return hipGetLastError();
 }
 
@@ -636,7 +642,6 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
                                uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean)
 {
     if (nblocks == 0) return hipSuccess;
-    if ((digest_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(digests) & 15)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((nblocks + CW_SKEIN_THREADS - 1) / CW_SKEIN_THREADS)), block(CW_SKEIN_THREADS);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
     const bool ragged = block_bytes == 0 || (block_bytes % (NW * 8)) != 0;
@@ -656,6 +661,8 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
     else if (aligned) CW_LAUNCH(true, true);
     else if (!ragged) CW_LAUNCH_LINES(false);
     else CW_LAUNCH(false, true);
+    note_kernels(1, NW == 8 ? (!ragged && !(aligned && steps) ? (aligned ? "cw::skein_lines_kernel<8, true>" : "cw::skein_lines_kernel<8, false>") : "cw::skein_blocks_kernel<8, ...>")
+                            : (!ragged && !(aligned && steps) ? (aligned ? "cw::skein_lines_kernel<4, true>" : "cw::skein_lines_kernel<4, false>") : "cw::skein_blocks_kernel<4, ...>"));
 #undef CW_LAUNCH
 #undef CW_LAUNCH_LINES
     return hipGetLastError();

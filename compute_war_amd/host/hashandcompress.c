@@ -20,8 +20,9 @@
  * Two ways onto the GPU, both through include/cw_hashcompress.h:
  *   --gpu-offload=false  workers call the slot-compatible functions per read unit, exactly where the
  *                        reference calls doCompression/doHashing (:250,:257);
- *   --gpu-offload=true   workers hand whole spans of read units to the batched entry point
- *                        cw_hash_and_compress_blocks (what HashOffload::Start/Complete were meant to be).
+ *   --gpu-offload=true   workers hand whole spans of read units to the pipelined batch entry point
+ *                        cw_hash_and_compress_packed (what HashOffload::Start/Complete were meant to be); the read
+ *                        units are page-locked once, outside the timed window, so the copy engines use them in place.
  */
 #define _GNU_SOURCE
 #include <getopt.h>
@@ -45,8 +46,14 @@ static int comp_alg = CW_COMP_LZ4, hash_alg = CW_HASH_SKEIN256_128;
 static uint8_t *data = NULL;
 static size_t n_units = 0, cap_units = 0, unit_bytes = 0;
 
-static size_t next_unit = 0; /* the queue: workers take the next unit (or span of units) */
+/* the queue: device g owns the units [shard_next[g], shard_end[g]) (contiguous shards); a worker takes the
+ * next unit (or span of units) of its device's shard */
+#define MAX_DEVICES 16
+static int n_devices = 1, devices_given = 0;
+static size_t shard_next[MAX_DEVICES], shard_end[MAX_DEVICES];
+static uint64_t dev_in[MAX_DEVICES], dev_out[MAX_DEVICES];
 static pthread_mutex_t q_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_barrier_t start_bar; /* workers set up (device context, buffers) in front of it; the timed window opens behind it */
 
 static uint64_t total_comp = 0, digest_fold = 0;
 static pthread_mutex_t r_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -64,6 +71,7 @@ static void usage(const char *n, const char *msg)
             "  -C, --comp-alg A       lzf | lz4 (default lz4)\n"
             "  -H, --hash-alg A       skein | sha256mb | skein512 (default skein)\n"
             "  -b, --block-size N     block size in bytes (default 4096)\n"
+            "  -D, --devices N        GPUs to shard the read units over (default 1)\n"
             "  -v, --verify           also print total compressed bytes and a digest fold\n",
             n);
     exit(msg ? 1 : 0);
@@ -123,33 +131,41 @@ static void process_unit_slots(const uint8_t *unit, uint8_t *hashes, uint8_t *co
 
 static void *worker(void *arg)
 {
-    (void)arg;
+    const int dev = (int)(intptr_t)arg;
     const size_t db = cw_digest_bytes(hash_alg);
     const size_t bound = cw_compress_bound(comp_alg, block_size);
-    /* offload path: a span of units per call keeps the device busy; slot path: one unit, like the reference */
-    size_t span = gpu_offload ? ((size_t)64 << 20) / unit_bytes : 1;
+    /* offload path: a span of units per call keeps the device's pipeline busy; slot path: one unit, like the reference */
+    size_t span = gpu_offload ? ((size_t)256 << 20) / unit_bytes : 1;
     if (span == 0) span = 1;
     const size_t span_blocks = span * (size_t)read_block_factor;
+    if (cw_set_device(dev) != CW_OK) { fprintf(stderr, "libcwhc: %s\n", cw_last_error()); exit(2); }
     uint8_t *hashes = (uint8_t *)malloc(db * span_blocks);
-    uint8_t *compressed = (uint8_t *)malloc((gpu_offload ? bound : 2 * block_size) * span_blocks);
+    /* offload: one packed stream in page-locked memory (the device-to-host copy lands in place); slots: the reference's 2*l each */
+    uint8_t *compressed = gpu_offload ? (uint8_t *)cw_host_alloc(bound * span_blocks) : (uint8_t *)malloc(2 * block_size * span_blocks);
     uint32_t *sizes = (uint32_t *)malloc(sizeof(uint32_t) * span_blocks);
-    uint64_t comp = 0, fold = 0;
-    if (!hashes || !compressed || !sizes) { fprintf(stderr, "out of memory\n"); exit(1); }
+    uint64_t *offsets = (uint64_t *)malloc(sizeof(uint64_t) * (span_blocks + 1));
+    uint64_t comp = 0, fold = 0, in = 0;
+    if (!hashes || !compressed || !sizes || !offsets) { fprintf(stderr, "out of memory\n"); exit(1); }
+    /* initializeGpu() (:95-98) per worker: context and batch buffers exist before the clock starts, as the reference's
+     * device setup would (it sits in front of the reads, :381-383) */
+    if (gpu_offload && cw_prepare(hash_alg, comp_alg, block_size, span_blocks, 1) != CW_OK) { fprintf(stderr, "libcwhc: %s\n", cw_last_error()); exit(2); }
+    pthread_barrier_wait(&start_bar);
 
     for (;;) {
         pthread_mutex_lock(&q_lock);
-        size_t first = next_unit;
-        size_t n = n_units - first < span ? n_units - first : span;
-        next_unit += n;
+        size_t first = shard_next[dev];
+        size_t n = shard_end[dev] - first < span ? shard_end[dev] - first : span;
+        shard_next[dev] += n;
         pthread_mutex_unlock(&q_lock);
         if (n == 0) break;
+        in += n * unit_bytes;
 
         if (!gpu_offload) {
             process_unit_slots(data + first * unit_bytes, hashes, compressed, &comp, &fold);
         } else {
             const size_t nb = n * (size_t)read_block_factor;
-            int rc = cw_hash_and_compress_blocks(hash_alg, comp_alg, data + first * unit_bytes, block_size, nb, hashes,
-                                                 compressed, bound, sizes);
+            int rc = cw_hash_and_compress_packed(hash_alg, comp_alg, data + first * unit_bytes, block_size, nb, hashes, compressed,
+                                                 bound * span_blocks, offsets, sizes);
             if (rc != CW_OK) { fprintf(stderr, "libcwhc: %s\n", cw_last_error()); exit(2); }
             for (size_t i = 0; i < nb; i++) comp += sizes[i] ? sizes[i] : block_size;
             fold_digests(hashes, db * nb, &fold);
@@ -158,9 +174,36 @@ static void *worker(void *arg)
     pthread_mutex_lock(&r_lock);
     total_comp += comp;
     digest_fold ^= fold;
+    dev_in[dev] += in;
+    dev_out[dev] += comp;
     pthread_mutex_unlock(&r_lock);
-    free(hashes); free(compressed); free(sizes);
+    free(hashes); free(sizes); free(offsets);
+    if (gpu_offload) cw_host_free(compressed); else free(compressed);
     return NULL;
+}
+
+/* the per-device byte totals, summed over the devices with RCCL (ncclAllReduce over xGMI): every device ends up with
+ * the node's totals, device 0's copy is reported */
+static int gather_totals(uint64_t out[2])
+{
+    int devs[MAX_DEVICES];
+    uint64_t *d_tot[MAX_DEVICES];
+    for (int g = 0; g < n_devices; g++) devs[g] = g;
+    cw_mgpu_t *mg = cw_mgpu_create(devs, n_devices);
+    if (!mg) { fprintf(stderr, "libcwhc: %s\n", cw_mgpu_last_error()); return -1; }
+    for (int g = 0; g < n_devices; g++) {
+        const uint64_t t[2] = {dev_in[g], dev_out[g]};
+        if (cw_set_device(g) != CW_OK || !(d_tot[g] = (uint64_t *)cw_dev_alloc(sizeof t)) || cw_dev_upload(d_tot[g], t, sizeof t) != CW_OK) {
+            fprintf(stderr, "libcwhc: %s\n", cw_last_error());
+            return -1;
+        }
+    }
+    int rc = cw_mgpu_gather(mg, NULL, 0, NULL, d_tot, 2);
+    if (rc != CW_OK) fprintf(stderr, "libcwhc: %s\n", cw_mgpu_last_error());
+    if (rc == CW_OK && (cw_set_device(0) != CW_OK || cw_dev_download(out, d_tot[0], 2 * sizeof(uint64_t)) != CW_OK)) rc = -1;
+    for (int g = 0; g < n_devices; g++) { (void)cw_set_device(g); cw_dev_free(d_tot[g]); }
+    cw_mgpu_destroy(mg);
+    return rc;
 }
 
 int main(int argc, char **argv)
@@ -170,9 +213,10 @@ int main(int argc, char **argv)
         {"gpu-offload", required_argument, 0, 'g'}, {"read-blocks", required_argument, 0, 'r'},
         {"hash-blocks", required_argument, 0, 'G'}, {"comp-alg", required_argument, 0, 'C'},
         {"hash-alg", required_argument, 0, 'H'},  {"block-size", required_argument, 0, 'b'},
-        {"verify", no_argument, 0, 'v'},         {0, 0, 0, 0}};
+        {"verify", no_argument, 0, 'v'},         {"devices", required_argument, 0, 'D'},
+        {0, 0, 0, 0}};
     int o;
-    while ((o = getopt_long(argc, argv, "hc:g:r:G:C:H:b:v", opts, NULL)) != -1) {
+    while ((o = getopt_long(argc, argv, "hc:g:r:G:C:H:b:vD:", opts, NULL)) != -1) {
         switch (o) {
         case 'h': usage(argv[0], NULL); break;
         case 'c': n_threads = atoi(optarg); break;
@@ -183,6 +227,7 @@ int main(int argc, char **argv)
         case 'H': hash_name = optarg; break;
         case 'b': block_size = (size_t)atol(optarg); break;
         case 'v': verify = 1; break;
+        case 'D': n_devices = atoi(optarg); devices_given = 1; break;
         default: usage(argv[0], "invalid option");
         }
     }
@@ -195,11 +240,14 @@ int main(int argc, char **argv)
     else usage(argv[0], "invalid hashing algorithm specified; please use either \"skein\" or \"sha256mb\"");
     if (n_threads < 1 || read_block_factor < 1 || block_size < 1 || block_size > CW_MAX_BLOCK_BYTES)
         usage(argv[0], "threads and read-blocks must be >= 1, block-size in 1..65536");
+    if (n_devices < 1 || n_devices > MAX_DEVICES) usage(argv[0], "devices must be 1..16");
+    if (n_threads < n_devices) n_threads = n_devices; /* every device needs a worker */
 
-    if (cw_init(0) != CW_OK) { /* initializeGpu() (:95-98); there is no CPU path to fall back to */
-        fprintf(stderr, "libcwhc: %s\n", cw_last_error());
-        return 2;
-    }
+    for (int g = 0; g < n_devices; g++)
+        if (cw_init(g) != CW_OK) { /* initializeGpu() (:95-98), per device; there is no CPU path to fall back to */
+            fprintf(stderr, "libcwhc: %s\n", cw_last_error());
+            return 2;
+        }
     cw_set_block_size(block_size);
     unit_bytes = block_size * (size_t)read_block_factor;
 
@@ -208,10 +256,15 @@ int main(int argc, char **argv)
     for (int i = optind; i < argc; i++) read_file(argv[i]);
 
     const uint64_t total_data = (uint64_t)unit_bytes * n_units;
+    for (int g = 0; g < n_devices; g++) cw_shard_range(n_units, g, n_devices, &shard_next[g], &shard_end[g]);
+    /* like the reads, page-locking the read units is preparation, not work: outside the timed window (:391-397) */
+    const int locked = gpu_offload && n_units && cw_host_register(data, n_units * unit_bytes) == CW_OK;
     struct timespec t0, t1;
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    pthread_barrier_init(&start_bar, NULL, (unsigned)n_threads + 1);
+    for (int t = 0; t < n_threads; t++) pthread_create(&tid[t], NULL, worker, (void *)(intptr_t)(t % n_devices));
+    pthread_barrier_wait(&start_bar); /* every worker is set up */
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int t = 0; t < n_threads; t++) pthread_create(&tid[t], NULL, worker, NULL);
     for (int t = 0; t < n_threads; t++) pthread_join(tid[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
 
@@ -222,6 +275,13 @@ int main(int argc, char **argv)
     if (verify)
         printf("blocks=%llu in=%llu out=%llu fold=%016llx\n", (unsigned long long)(n_units * (size_t)read_block_factor),
                (unsigned long long)total_data, (unsigned long long)total_comp, (unsigned long long)digest_fold);
+    if (devices_given) { /* the node's totals as the devices hold them after the RCCL reduction */
+        uint64_t t[2] = {0, 0};
+        if (gather_totals(t) != CW_OK) return 2;
+        printf("devices=%d in=%llu out=%llu (ncclAllReduce over the per-device totals)\n", n_devices, (unsigned long long)t[0], (unsigned long long)t[1]);
+        if (t[0] != total_data || t[1] != total_comp) { fprintf(stderr, "device totals disagree with the host's\n"); return 3; }
+    }
+    if (locked) (void)cw_host_unregister(data);
     cw_shutdown();
     free(tid);
     free(data);

@@ -35,6 +35,19 @@ def shutdown() -> None:
     lib().cw_shutdown()
 
 
+def set_device(device: int) -> None:
+    """The calling thread's device for its next calls (initialises it if needed)."""
+    check(lib().cw_set_device(device))
+
+
+def get_device() -> int:
+    return int(lib().cw_get_device())
+
+
+def device_count() -> int:
+    return int(lib().cw_device_count())
+
+
 def set_block_size(n: int) -> None:
     lib().cw_set_block_size(n)
 
@@ -155,6 +168,36 @@ def hash_and_compress_blocks(hash_alg, comp_alg, src, block_bytes: int):
     return digests, sizes, payload
 
 
+def hash_and_compress_packed(hash_alg, comp_alg, src, block_bytes: int, pinned: bool = False):
+    """cw_hash_and_compress_packed: (digests[n, db], sizes[n], offsets[n + 1], packed[total] uint8).  pinned=True takes the
+    input and the packed output through page-locked buffers (cw_host_alloc), the zero-copy form of the pipeline."""
+    a = _np_u8(src)
+    n = a.size // block_bytes
+    hid, cid = _hash_id(hash_alg), _comp_id(comp_alg)
+    cap = max(n * compress_bound(cid, block_bytes), 1)
+    digests = np.zeros((n, digest_bytes(hid)), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    if pinned:
+        hp, hs = lib().cw_host_alloc(cap), lib().cw_host_alloc(max(a.size, 1))
+        if not hp or not hs:
+            raise _lib.CwError(-5, lib().cw_last_error().decode())
+        try:
+            C.memmove(hs, a.ctypes.data, a.size)
+            check(lib().cw_hash_and_compress_packed(hid, cid, hs, block_bytes, n, digests.ctypes.data, hp, cap, offsets.ctypes.data,
+                                                    sizes.ctypes.data))
+            packed = np.ctypeslib.as_array((C.c_uint8 * int(offsets[n])).from_address(hp)).copy() if offsets[n] else np.zeros(0, np.uint8)
+        finally:
+            lib().cw_host_free(hp)
+            lib().cw_host_free(hs)
+    else:
+        buf = np.zeros(cap, dtype=np.uint8)
+        check(lib().cw_hash_and_compress_packed(hid, cid, a.ctypes.data, block_bytes, n, digests.ctypes.data, buf.ctypes.data, cap,
+                                                offsets.ctypes.data, sizes.ctypes.data))
+        packed = buf[: int(offsets[n])].copy()
+    return digests, sizes, offsets, packed
+
+
 # ---- device-resident API (raw pointers) ------------------------------------------------------------
 def dev_hash(alg, d_src: int, block_bytes: int, nblocks: int, d_digests: int, stream: int = 0,
              src_stride: int | None = None) -> None:
@@ -187,6 +230,11 @@ def dev_gen_random(seed: int, first_block: int, nblocks: int, block_bytes: int, 
     check(lib().cw_dev_gen_random(seed, first_block, nblocks, block_bytes, d_dst, stream))
 
 
+def dev_gen_mixed(seed: int, first_block: int, nblocks: int, block_bytes: int, d_dst: int, stream: int = 0) -> None:
+    """SURVEY 8(d)'s compressible mix: even blocks random, odd blocks a 64-byte motif with 1/16 of the bytes mutated."""
+    check(lib().cw_dev_gen_mixed(seed, first_block, nblocks, block_bytes, d_dst, stream))
+
+
 def dev_sum_sizes(d_sizes: int, nblocks: int, raw_bytes: int, d_totals: int, stream: int = 0) -> None:
     check(lib().cw_dev_sum_sizes(d_sizes, nblocks, raw_bytes, d_totals, stream))
 
@@ -203,11 +251,21 @@ def profile_read(reset: bool = True) -> dict:
     return {k: (ms[i], cnt[i]) for i, k in enumerate(("codec", "hash", "other"))}
 
 
+def profile_kernels() -> dict:
+    """Names of the kernels the calling thread's latest codec / hash launch used (as rocprofv3 prints them)."""
+    out = {}
+    for i, k in enumerate(("codec", "hash")):
+        buf = C.create_string_buffer(256)
+        check(lib().cw_profile_kernels(i, buf, 256))
+        out[k] = buf.value.decode()
+    return out
+
+
 # ---- HashOffload ------------------------------------------------------------------------------------
 class HashOffload:
     """HashOffload.h:13-64: Reset(data, results, onComplete) -> Enqueue() -> Start() -> Complete()."""
 
-    hInit, hQueued, hOffloaded, hComplete = 0, 1, 2, 3
+    hInit, hQueued, hOffloaded, hComplete, hFailed = 0, 1, 2, 3, 4
 
     def __init__(self, n_blocks: int, alg="skein", block_bytes: int = 4096):
         self._h = lib().cw_offload_create(_hash_id(alg), n_blocks, block_bytes)
@@ -243,6 +301,11 @@ class HashOffload:
     @property
     def state(self) -> int:
         return int(lib().cw_offload_state(self._h))
+
+    @property
+    def error(self) -> int:
+        """CW_OK, or the status code that put the object into hFailed."""
+        return int(lib().cw_offload_error(self._h))
 
     def close(self) -> None:
         if self._h:

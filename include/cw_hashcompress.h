@@ -16,7 +16,13 @@
  *
  * Threading: every function may be called concurrently from any number of host threads
  * (the reference calls its slots from --c-threads workers, :398-402); each calling thread
- * gets its own HIP stream and staging buffers.
+ * gets its own HIP streams and staging buffers per device.  The cw_dev_* functions may also be
+ * called from several threads on the SAME stream: each call's launch sequence is queued
+ * atomically (a per-(device, stream) mutex), so the calls execute in some serial order.
+ *
+ * Devices: cw_init(d) / cw_set_device(d) initialise device d (if needed) and make it the calling
+ * thread's device; threads that never choose use the first initialised device.  Device pointers
+ * and streams passed to cw_dev_* must belong to the calling thread's device.
  *
  * There is NO CPU fallback: every compute entry point fails (CW_ERR_NO_DEVICE / abort in the
  * void slot wrappers) when no gfx950 device is usable.
@@ -57,9 +63,11 @@ typedef enum cw_comp_alg {
 } cw_comp_alg;
 
 /* ---- lifecycle: initializeGpu() (:95-98) and the shutdown hook (:182) ----------------------- */
-int  cw_init(int device);            /* select + warm the device; idempotent; CW_OK or CW_ERR_* */
-void cw_shutdown(void);
+int  cw_init(int device);            /* initialise `device` (idempotent) and make it the calling thread's device */
+void cw_shutdown(void);              /* every initialised device: synchronise, free the library's scratch */
 int  cw_device_count(void);          /* usable gfx950 devices (0 when none) */
+int  cw_set_device(int device);      /* = cw_init: the device the calling thread's next calls run on (--devices) */
+int  cw_get_device(void);            /* the calling thread's device, -1 before any cw_init */
 const char *cw_last_error(void);     /* message of the calling thread's last failure */
 const char *cw_version(void);
 
@@ -103,6 +111,24 @@ int cw_compress_blocks(int comp_alg, const void *src, size_t block_bytes, size_t
 int cw_hash_and_compress_blocks(int hash_alg, int comp_alg, const void *src, size_t block_bytes,
                                 size_t nblocks, void *digests, void *dst, size_t dst_stride,
                                 uint32_t *sizes);
+/* Same work, packed output: the compressed blocks arrive as ONE stream (block i at packed + offsets[i], sizes[i] bytes;
+ * offsets has nblocks + 1 entries, the last one the total; a block that did not fit occupies nothing) -- the device
+ * packs the slots (cw_dev_pack) so only compressed bytes cross the bus, and with a page-locked `packed` buffer they land
+ * in place with no copy on the host.  packed_cap must cover the total (nblocks * cw_compress_bound() always does). */
+int cw_hash_and_compress_packed(int hash_alg, int comp_alg, const void *src, size_t block_bytes,
+                                size_t nblocks, void *digests, void *packed, size_t packed_cap,
+                                uint64_t *offsets, uint32_t *sizes);
+/* Both forms run as a three-stage pipeline (host->device copy of chunk k+1 | kernels of chunk k | device->host copy of
+ * chunk k-1: what HashOffload::Start()/Complete() were meant to be, HashOffload.h:26-40).  The copy engines read and
+ * write page-locked host memory in place; other buffers go through pinned staging with one memcpy.  To get buffers
+ * the engines can use directly:                                                                                    */
+/* initializeGpu() (:95-98) for the calling thread: its context on its device plus everything the batch path would allocate
+ * on first use for batches of up to nblocks blocks (pinned_io: the caller's buffers are page-locked, no staging needed) */
+int   cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, int pinned_io);
+void *cw_host_alloc(size_t bytes);               /* page-locked host memory (NULL on failure) */
+void  cw_host_free(void *p);
+int   cw_host_register(void *p, size_t bytes);   /* page-lock an existing buffer (e.g. the driver's read units) */
+int   cw_host_unregister(void *p);
 /* decode nblocks slots (comp_stride apart, sizes[i] bytes each) into nblocks * block_bytes at dst;
  * status[i] = 0 iff slot i is well formed and yields exactly block_bytes (see cw_dev_decompress).  */
 /* host-buffer form of cw_dev_hash_tree */
@@ -144,22 +170,38 @@ int cw_dev_pack(const void *d_slots, size_t slot_stride, const uint32_t *d_sizes
 /* synthetic input: u64 word w of block b = splitmix64(seed ^ (b << 13 | w)) */
 int cw_dev_gen_random(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes,
                       void *d_dst, void *stream);
+/* compressible synthetic mix: even blocks as cw_dev_gen_random, odd blocks = a 64-byte motif repeated with
+ * every byte replaced by a random one with probability 1/16 (exact definition: csrc/misc_kernels.hip, host twin
+ * oracle/hc_oracle.c) -- so that the codecs' match/emit loops are timed, not only their incompressible fast path */
+int cw_dev_gen_mixed(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes,
+                     void *d_dst, void *stream);
 /* d_totals[0] += sum of sizes (a 0 counts as raw_bytes: stored uncompressed); d_totals[1] += #zeros */
 int cw_dev_sum_sizes(const uint32_t *d_sizes, size_t nblocks, uint32_t raw_bytes, uint64_t *d_totals,
                      void *stream);
+
+/* plain device memory on the calling thread's device, for C callers of cw_dev_* (the host programs link no HIP runtime) */
+void *cw_dev_alloc(size_t bytes);                                   /* NULL on failure */
+void  cw_dev_free(void *d_p);
+int   cw_dev_upload(void *d_dst, const void *src, size_t bytes);    /* synchronous copies */
+int   cw_dev_download(void *dst, const void *d_src, size_t bytes);
+int   cw_dev_synchronize(void);                                     /* all work queued on the calling thread's device */
 
 /* ---- kernel timing (the reference times with std::chrono around its calls, hash.cpp:11-18, HashAndCompress.cpp:397-406;
  *      device work is asynchronous, so the library brackets its own launches with HIP events on the stream each
  *      kernel is launched on).  Per calling thread.  Kinds: [0] codec kernels, [1] hash kernel, [2] reserved.       */
 void cw_profile_enable(int on);
 int  cw_profile_read(double ms_sum[3], unsigned count[3], int reset);   /* synchronises on the recorded events */
+/* names of the kernels the calling thread's latest codec (kind 0) / hash (kind 1) launch used, as rocprofv3 prints them */
+int  cw_profile_kernels(int kind, char *buf, size_t cap);
 
 /* ---- HashOffload (HashOffload.h:13-64): batch object + the offload thread that drains it -------
  * Lifecycle  hInit --Enqueue--> hQueued --Start--> hOffloaded --Complete--> hComplete.
  * Start() = "xfer data, load kernel" (:26-31): async H2D + hash kernel + async D2H on the object's stream.
  * Complete() = "wait for and reap the results" (:33-40): blocks, then runs on_complete(arg).       */
 typedef struct cw_offload cw_offload_t;
-enum { CW_OFFLOAD_INIT = 0, CW_OFFLOAD_QUEUED = 1, CW_OFFLOAD_OFFLOADED = 2, CW_OFFLOAD_COMPLETE = 3 };
+enum { CW_OFFLOAD_INIT = 0, CW_OFFLOAD_QUEUED = 1, CW_OFFLOAD_OFFLOADED = 2, CW_OFFLOAD_COMPLETE = 3,
+       CW_OFFLOAD_FAILED = 4 /* Start()/Complete() failed: nothing is in flight, cw_offload_error() says why;
+                                Reset() makes the object usable again */ };
 
 cw_offload_t *cw_offload_create(int hash_alg, int n_blocks, size_t block_bytes);   /* HashOffload(int nBlocks) */
 void cw_offload_destroy(cw_offload_t *h);
@@ -170,12 +212,37 @@ int  cw_offload_start(cw_offload_t *h);                                         
 int  cw_offload_complete(cw_offload_t *h);                                         /* Complete() */
 int  cw_offload_completed(const cw_offload_t *h);                                  /* Completed() */
 int  cw_offload_state(const cw_offload_t *h);
+int  cw_offload_error(const cw_offload_t *h);                                      /* CW_OK, or why the state is hFailed */
 int  cw_offload_do(cw_offload_t *h);                                               /* DoOffload() */
 
 /* hashing_offload_entry_point (:160-183): one consumer thread popping a queue of HashOffload* */
 int  cw_offload_thread_start(void);
-int  cw_offload_submit(cw_offload_t *h);   /* Enqueue() + push + notify (the producer the reference never wrote) */
+int  cw_offload_submit(cw_offload_t *h);   /* Enqueue() + push + notify (the producer the reference never wrote);
+                                              on_complete runs on the offload thread also when the offload FAILED --
+                                              check cw_offload_completed() / cw_offload_error() in it */
 void cw_offload_thread_stop(void);         /* allWorkFinished = true; join */
+
+/* ---- several GPUs of one node (BASELINE.json configs[4]) ----------------------------------------------
+ * The reference's only parallelism is worker threads over independent blocks (HashAndCompress.cpp:398-403); its dormant
+ * --gpu-offload seam (:305,331) has one device at most.  Here the block index space is cut into contiguous shards, one
+ * per device, each processed with the single-device entry points above (one host thread per device, cw_set_device);
+ * the only exchange is the result gather after a pass, over RCCL (xGMI between the GPUs of the node):
+ * ncclAllGather of the digests, ncclAllReduce(sum, u64) of the byte totals.  RCCL is loaded (dlopen) by cw_mgpu_create
+ * only.                                                                                                             */
+/* shard g of G over n units: [*first, *last) = [g*n/G, (g+1)*n/G) */
+void cw_shard_range(size_t n, int g, int G, size_t *first, size_t *last);
+typedef struct cw_mgpu cw_mgpu_t;
+cw_mgpu_t *cw_mgpu_create(const int *devices, int ndev);   /* cw_init on each + ncclCommInitAll; NULL on failure */
+void cw_mgpu_destroy(cw_mgpu_t *m);
+int  cw_mgpu_ndev(const cw_mgpu_t *m);
+int  cw_mgpu_device(const cw_mgpu_t *m, int rank);
+const char *cw_mgpu_last_error(void);
+/* The gather: rank g contributes bytes_each bytes at d_local[g] (its shard's digests, padded to the largest shard) and
+ * ntotals u64 at d_totals[g]; afterwards d_all[g] on EVERY device holds all ranks' contributions in rank order
+ * (ndev * bytes_each bytes) and d_totals[g] the element-wise sums.  The work that produced the inputs must be complete
+ * (synchronise its streams first).  Either half may be skipped (bytes_each = 0 / ntotals = 0).  Blocking.            */
+int  cw_mgpu_gather(cw_mgpu_t *m, const void *const *d_local, size_t bytes_each, void *const *d_all,
+                    uint64_t *const *d_totals, size_t ntotals);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
         L.cw_oracle_lz4_bound.argtypes = [C.c_size_t]
         L.cw_oracle_lz4_bound.restype = C.c_size_t
         L.cw_oracle_gen_random_blocks.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, u8p]
+        L.cw_oracle_gen_mixed_blocks.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, u8p]
         L.cw_oracle_digest_bytes.argtypes = [C.c_int]
         L.cw_oracle_digest_bytes.restype = C.c_size_t
         L.cw_oracle_hash_and_compress.argtypes = [u8p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -146,6 +147,12 @@ def lzf_decompress(data, cap: int) -> bytes | None:
 def gen_random_blocks(seed: int, first_block: int, nblocks: int, block_bytes: int) -> np.ndarray:
     out = np.zeros(nblocks * block_bytes, dtype=np.uint8)
     lib().cw_oracle_gen_random_blocks(seed, first_block, nblocks, block_bytes, _ptr(out))
+    return out
+
+
+def gen_mixed_blocks(seed: int, first_block: int, nblocks: int, block_bytes: int) -> np.ndarray:
+    out = np.zeros(nblocks * block_bytes, dtype=np.uint8)
+    lib().cw_oracle_gen_mixed_blocks(seed, first_block, nblocks, block_bytes, _ptr(out))
     return out
 
 

@@ -58,6 +58,10 @@ long   cw_oracle_lzf_decompress(const uint8_t *src, size_t n, uint8_t *dst, size
 void cw_oracle_gen_random_blocks(uint64_t seed, uint64_t first_block, size_t nblocks,
                                  size_t block_bytes, uint8_t *dst);
 
+/* compressible mix: even blocks as above, odd blocks = 64-byte motif with 1/16 of the bytes mutated */
+void cw_oracle_gen_mixed_blocks(uint64_t seed, uint64_t first_block, size_t nblocks,
+                                size_t block_bytes, uint8_t *dst);
+
 /* ---- batched per-block drivers (the CPU "hashandcompress" worker loop) --- */
 enum { CW_OR_HASH_SKEIN512 = 0, CW_OR_HASH_SKEIN256_128 = 1, CW_OR_HASH_SHA256 = 2, CW_OR_HASH_NONE = 3 };
 enum { CW_OR_COMP_LZ4 = 0, CW_OR_COMP_LZF = 1, CW_OR_COMP_NONE = 2 };

@@ -36,6 +36,32 @@ void cw_oracle_gen_random_blocks(uint64_t seed, uint64_t first_block, size_t nbl
     }
 }
 
+/* host twin of gen_mixed_kernel (compute_war_amd/csrc/misc_kernels.hip): SURVEY.md 8(d)'s compressible mix */
+static uint64_t mixed_word(uint64_t seed, uint64_t blk, uint64_t w)
+{
+    const uint64_t salt_motif = 0x6D6F746966ULL, salt_mutate = 0x6D7574617465ULL;
+    uint64_t m, r, r2, mask = 0;
+    if ((blk & 1) == 0) return splitmix64(seed ^ ((blk << 13) | w));
+    m = splitmix64(seed ^ salt_motif ^ ((blk << 13) | (w & 7)));
+    r = splitmix64(seed ^ salt_mutate ^ ((blk << 13) | w));
+    r2 = splitmix64(r);
+    for (int k = 0; k < 8; k++) if (((r >> (4 * k)) & 15) == 0) mask |= 0xFFULL << (8 * k);
+    return (m & ~mask) | (r2 & mask);
+}
+
+void cw_oracle_gen_mixed_blocks(uint64_t seed, uint64_t first_block, size_t nblocks,
+                                size_t block_bytes, uint8_t *dst)
+{
+    const size_t words = block_bytes / 8;
+    for (size_t b = 0; b < nblocks; b++) {
+        uint8_t *p = dst + b * block_bytes;
+        for (size_t w = 0; w < words; w++) {
+            uint64_t v = mixed_word(seed, first_block + b, (uint64_t)w);
+            for (int k = 0; k < 8; k++) p[8 * w + k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+}
+
 size_t cw_oracle_digest_bytes(int hash_alg)
 {
     switch (hash_alg) {

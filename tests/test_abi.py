@@ -90,3 +90,36 @@ def test_host_driver_builds_and_refuses_without_gpu(cwlib):
     if not torch.cuda.is_available():
         r = subprocess.run([exe, os.path.join(ROOT, "tests/golden/corpus/canterbury/alice29.txt")], capture_output=True, text=True)
         assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_shard_range_from_c_matches_python(cwlib):
+    """cw_shard_range (the C side of SURVEY 8e's contiguous g*N/G shards) against compute_war_amd.shard.shard_range,
+    incl. two "fake devices": no GPU is needed for the sharding logic."""
+    import ctypes as C
+    from compute_war_amd.shard import shard_range
+    L = cwlib.lib()
+    for n in (0, 1, 7, 136, 1000, (1 << 20) + 3, 1 << 40):
+        for G in (1, 2, 3, 8):
+            prev = 0
+            for g in range(G):
+                a, b = C.c_size_t(), C.c_size_t()
+                L.cw_shard_range(n, g, G, C.byref(a), C.byref(b))
+                assert (a.value, b.value) == shard_range(n, g, G) and a.value == prev
+                prev = b.value
+            assert prev == n
+
+
+def test_multi_device_entry_points_fail_cleanly_without_gpu(cwlib):
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = cwlib.lib()
+    devs = (C.c_int * 2)(0, 1)
+    assert not L.cw_mgpu_create(devs, 2) and b"no HIP device" in L.cw_mgpu_last_error()
+    assert L.cw_set_device(1) != 0 and L.cw_get_device() == -1
+    assert not L.cw_dev_alloc(16) and not L.cw_host_alloc(16)
+    exe = os.path.join(ROOT, "compute_war_amd", "host", "mgpu_stream")
+    subprocess.run(["make", "-C", os.path.dirname(exe)], capture_output=True, text=True, check=True)
+    r = subprocess.run([exe, "--devices", "2"], capture_output=True, text=True)
+    assert r.returncode == 2 and "0 usable" in r.stderr

@@ -1,0 +1,286 @@
+"""Round-2 additions, on the GPU: the pipelined host batch path (slots and packed stream, pinned and pageable buffers,
+several chunks in flight), the compressible synthetic mix, two host threads on ONE stream, HashOffload's failure state,
+digests at any alignment, decoders fed impossible sizes, the alternative LZ4 parser, per-device contexts and the C
+multi-GPU harness with the one device the box has."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, corpus_file
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cw():
+    import compute_war_amd as cw
+    cw.init(0)
+    return cw
+
+
+def _mixed_corpus(nbytes):
+    t = corpus_file("lcet10.txt") + corpus_file("kennedy.xls")[:300000] + bytes(70000) + corpus_file("ptt5")[:200000]
+    noise = np.random.default_rng(7).integers(0, 256, 200000, dtype=np.uint8).tobytes()
+    t = t + noise
+    return (t * (nbytes // len(t) + 1))[:nbytes]
+
+
+def _check_packed(oracle, data, bs, hash_alg, comp, digests, sizes, offsets, packed):
+    hfn = {"skein512": lambda b: oracle.skein512(b, 512), "skein": lambda b: oracle.skein256(b, 128), "sha256mb": oracle.sha256}[hash_alg]
+    cfn = oracle.lz4_compress if comp == "lz4" else oracle.lzf_compress
+    n = len(data) // bs
+    assert offsets[0] == 0 and len(offsets) == n + 1
+    for i in range(n):
+        b = data[i * bs:(i + 1) * bs]
+        want = cfn(b)
+        assert sizes[i] == len(want), (i, sizes[i], len(want))
+        assert offsets[i + 1] - offsets[i] == len(want)
+        assert packed[int(offsets[i]):int(offsets[i + 1])].tobytes() == want, i
+        assert digests[i].tobytes() == hfn(b), i
+    assert int(offsets[n]) == len(packed)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("hash_alg,comp,bs", [("skein512", "lz4", 65536), ("sha256mb", "lzf", 4096), ("skein", "lz4", 4096)])
+def test_host_pipeline_packed_matches_oracle(cw, oracle, hash_alg, comp, bs, pinned):
+    data = _mixed_corpus(3 * 1024 * 1024 + (bs if bs == 4096 else 0))
+    data = data[: len(data) // bs * bs]
+    d, sizes, offsets, packed = cw.hash_and_compress_packed(hash_alg, comp, data, bs, pinned=pinned)
+    _check_packed(oracle, data, bs, hash_alg, comp, d, sizes, offsets, packed)
+
+
+def test_host_pipeline_many_small_chunks_subprocess(oracle):
+    """CW_HOST_CHUNK_MB=1 (read once per process): a 9 MiB batch becomes 9 chunks through the three slots -- slot reuse,
+    the packed stream's running offset and the slot form's scatter are all exercised; results against the oracle."""
+    prog = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, hashlib, compute_war_amd as cw\n"
+        "from test_gpu_round2 import _mixed_corpus\n"
+        "cw.init(0)\n"
+        "data = _mixed_corpus(9 * 1024 * 1024)\n"
+        "for comp, bs in (('lz4', 65536), ('lzf', 4096)):\n"
+        "    d, sizes, offsets, packed = cw.hash_and_compress_packed('skein512', comp, data, bs)\n"
+        "    d2, s2, payload = cw.hash_and_compress_blocks('skein512', comp, data, bs)\n"
+        "    assert np.array_equal(d, d2) and np.array_equal(sizes, s2)\n"
+        "    for i in range(len(sizes)): assert payload[i, :sizes[i]].tobytes() == packed[int(offsets[i]):int(offsets[i+1])].tobytes(), i\n"
+        "    print(comp, bs, hashlib.sha256(d.tobytes() + sizes.tobytes() + packed.tobytes()).hexdigest())\n" % (ROOT, ROOT))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env={**os.environ, "CW_HOST_CHUNK_MB": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    import hashlib
+    data = _mixed_corpus(9 * 1024 * 1024)
+    lines = r.stdout.strip().splitlines()
+    for line, (comp, bs) in zip(lines, (("lz4", 65536), ("lzf", 4096))):
+        cfn = oracle.lz4_compress if comp == "lz4" else oracle.lzf_compress
+        h = hashlib.sha256()
+        n = len(data) // bs
+        blocks = [data[i * bs:(i + 1) * bs] for i in range(n)]
+        outs = [cfn(b) for b in blocks]
+        h.update(b"".join(oracle.skein512(b, 512) for b in blocks))
+        h.update(np.array([len(o) for o in outs], dtype=np.uint32).tobytes())
+        h.update(b"".join(outs))
+        assert line.split()[-1] == h.hexdigest(), (comp, bs)
+
+
+def test_gen_mixed_matches_host_twin_and_compresses(cw, oracle):
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    for bs, nb, first in ((65536, 10, 0), (4096, 33, 5)):
+        buf = torch.zeros(nb * bs, dtype=torch.uint8, device="cuda")
+        cw.dev_gen_mixed(0xC0FFEE, first, nb, bs, buf.data_ptr(), s)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert np.array_equal(got, oracle.gen_mixed_blocks(0xC0FFEE, first, nb, bs))
+        # even blocks are the random stream, odd ones compress (motif + 1/16 mutations)
+        assert np.array_equal(got[:bs] if first % 2 == 0 else got[bs:2 * bs],
+                              oracle.gen_random_blocks(0xC0FFEE, first + first % 2, 1, bs))
+        sizes, payload = cw.compress_blocks("lz4", got, bs)
+        for i in range(nb):
+            want = oracle.lz4_compress(got[i * bs:(i + 1) * bs].tobytes())
+            assert sizes[i] == len(want) and payload[i, :sizes[i]].tobytes() == want
+            assert (sizes[i] < bs // 2) == ((first + i) % 2 == 1)
+
+
+def test_two_host_threads_on_one_stream(cw, oracle):
+    """scratch is keyed by stream; two threads calling the fused entry point on the SAME stream must not
+    interleave their launch sequences (per-(device, stream) launch mutex)."""
+    import torch
+    bs, nb = 65536, 24
+    stream = torch.cuda.Stream()
+    s = stream.cuda_stream
+    stride = (cw.compress_bound("lz4", bs) + 15) // 16 * 16
+    datas = [(_mixed_corpus(bs * nb + 977 * t))[977 * t: 977 * t + bs * nb] for t in range(2)]
+    bufs = []
+    for d in datas:
+        bufs.append(dict(src=torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda(), dig=torch.zeros(nb * 64, dtype=torch.uint8, device="cuda"),
+                         dst=torch.zeros(nb * stride, dtype=torch.uint8, device="cuda"), sizes=torch.zeros(nb, dtype=torch.int32, device="cuda")))
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(t):
+        try:
+            b = bufs[t]
+            for _ in range(20):
+                cw.dev_hash_and_compress("skein512", "lz4", b["src"].data_ptr(), bs, nb, b["dig"].data_ptr(), b["dst"].data_ptr(), stride,
+                                         b["sizes"].data_ptr(), s)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for t in range(2):
+        dig, dst, sizes = (bufs[t][k].cpu().numpy() for k in ("dig", "dst", "sizes"))
+        for i in range(nb):
+            blk = datas[t][i * bs:(i + 1) * bs]
+            want = oracle.lz4_compress(blk)
+            assert sizes[i] == len(want) and dst[i * stride:i * stride + len(want)].tobytes() == want, (t, i)
+            assert dig[64 * i:64 * i + 64].tobytes() == oracle.skein512(blk, 512), (t, i)
+
+
+def test_offload_failure_is_reported_not_swallowed(cw):
+    """Start() on an object whose Reset() gave no buffers must not leave it hOffloaded; through the offload
+    thread the waiter is still woken and finds the failure on the object."""
+    h = cw.HashOffload(8, "skein", 4096)
+    assert cw.lib().cw_offload_reset(h._h, None, None, cw._lib.ON_COMPLETE(lambda _a: None), None) == 0
+    h.Enqueue()
+    with pytest.raises(cw.CwError):
+        h.Start()
+    assert h.state == h.hFailed and h.error != 0 and not h.Completed()
+    with pytest.raises(cw.CwError):
+        h.Complete()
+    # through the consumer thread: the callback fires, the object says why
+    ev = threading.Event()
+    cb = cw._lib.ON_COMPLETE(lambda _a: ev.set())
+    assert cw.lib().cw_offload_reset(h._h, None, None, cb, None) == 0
+    assert h.state == h.hInit and h.error == 0
+    assert cw.lib().cw_offload_thread_start() == 0
+    h.Submit()
+    assert ev.wait(30)
+    cw.lib().cw_offload_thread_stop()
+    assert h.state == h.hFailed and not h.Completed()
+    # and the object works again after a proper Reset
+    data = np.random.default_rng(1).integers(0, 256, 8 * 4096, dtype=np.uint8)
+    res = np.zeros(8 * 16, dtype=np.uint8)
+    h.Reset(data, res)
+    h.Enqueue()
+    h.DoOffload()
+    assert h.Completed() and res.any()
+    h.close()
+
+
+def test_digests_at_any_alignment(cw, oracle):
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    bs, nb = 4096, 70
+    raw = np.random.default_rng(11).integers(0, 256, bs * nb, dtype=np.uint8)
+    src = torch.from_numpy(raw).cuda()
+    for alg, db in (("skein512", 64), ("skein", 16), ("sha256mb", 32)):
+        for shift in (1, 8):
+            dig = torch.zeros(nb * db + 32, dtype=torch.uint8, device="cuda")
+            cw.dev_hash(alg, src.data_ptr(), bs, nb, dig.data_ptr() + shift, s)
+            torch.cuda.synchronize()
+            hd = dig.cpu().numpy()
+            want = {"skein512": lambda b: oracle.skein512(b, 512), "skein": lambda b: oracle.skein256(b, 128), "sha256mb": oracle.sha256}[alg]
+            for i in (0, 1, 63, 64, nb - 1):
+                assert hd[shift + i * db: shift + (i + 1) * db].tobytes() == want(raw[i * bs:(i + 1) * bs].tobytes()), (alg, shift, i)
+
+
+def test_decoders_reject_sizes_beyond_the_slot(cw, oracle):
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    for bs in (4096, 65536):          # staged and unstaged decoder variants
+        blk = corpus_file("alice29.txt")[:bs]
+        for alg, comp in (("lz4", oracle.lz4_compress(blk)), ("lzf", oracle.lzf_compress(blk))):
+            stride = (cw.compress_bound(alg, bs) + 15) // 16 * 16
+            nb = 4
+            slots = np.zeros((nb, stride), dtype=np.uint8)
+            slots[:, : len(comp)] = np.frombuffer(comp, dtype=np.uint8)
+            d_slots = torch.from_numpy(slots.reshape(-1)).cuda()
+            sizes = np.array([len(comp), stride + 1, 0xFFFFFFF0, 1 << 25], dtype=np.uint32)   # ok, > slot, absurd, absurd
+            d_sizes = torch.from_numpy(sizes.view(np.int32)).cuda()
+            out = torch.zeros(nb * bs, dtype=torch.uint8, device="cuda")
+            st = torch.full((nb,), 7, dtype=torch.int32, device="cuda")
+            cw.dev_decompress(alg, d_slots.data_ptr(), stride, d_sizes.data_ptr(), nb, out.data_ptr(), bs, st.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert st.cpu().tolist() == [0, 1, 1, 1], (alg, bs)
+            assert out[:bs].cpu().numpy().tobytes() == blk
+
+
+def test_alternative_lz4_parser_is_exact():
+    """CW_LZ4_PARSE=fp (the fingerprint parser for blocks read from global memory; read once per process)."""
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, compute_war_amd as cw\n"
+        "from conftest import corpus_file\n"
+        "cw.init(0)\n"
+        "data = corpus_file('lcet10.txt')[:6*65536] + bytes(65536) + corpus_file('kennedy.xls')[:5*65536] + corpus_file('ptt5')[:3*65536]\n"
+        "for bs in (8192, 65536):\n"
+        "    sizes, payload = cw.compress_blocks('lz4', data, bs)\n"
+        "    h = hashlib.sha256(sizes.tobytes())\n"
+        "    for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
+        "    print(bs, int(sizes.sum()), h.hexdigest(), cw.profile_kernels()['codec'])\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({}, {"CW_LZ4_PARSE": "fp"}, {"CW_LZ4_PARSE": "fp", "CW_LZ4_HEADW": "32"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
+    for a, b, c in zip(*outs):
+        assert a[:3] == b[:3] == c[:3]
+        assert "lz4_parse_kernel<false>" in " ".join(a) and "lz4_parse_fp_kernel" in " ".join(b)
+
+
+def test_devices_and_contexts(cw):
+    assert cw.device_count() >= 1 and cw.get_device() == 0
+    cw.set_device(0)
+    with pytest.raises(cw.CwError):
+        cw.set_device(cw.device_count())     # not a silent no-op: out of range is an error
+    assert cw.get_device() == 0
+    names = cw.profile_kernels()
+    assert set(names) == {"codec", "hash"}
+
+
+def test_mgpu_stream_one_device(oracle):
+    """The C multi-GPU harness with the one device this box has: sharding, per-device worker, RCCL gather (one rank)."""
+    exe = os.path.join(ROOT, "compute_war_amd", "host", "mgpu_stream")
+    r = subprocess.run(["make", "-C", os.path.dirname(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    bs, nb = 65536, 300
+    r = subprocess.run([exe, "--devices", "1", "--blocks-per-gpu", str(nb), "--block-size", str(bs), "--steps", "2", "--warmup", "1",
+                        "--data", "mixed"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()   # RCCL announces itself (versions, host) on stdout: pick our lines by content
+    assert any(ln.startswith("skein512|lz4|") for ln in lines)
+    rep = json.loads(next(ln for ln in lines if ln.startswith("{")))
+    data = oracle.gen_mixed_blocks(0xC0FFEE, 0, nb, bs)
+    out = sum(len(oracle.lz4_compress(data[i * bs:(i + 1) * bs].tobytes())) for i in range(nb))
+    fold = np.uint64(0)
+    for i in range(nb):
+        fold ^= np.bitwise_xor.reduce(np.frombuffer(oracle.skein512(data[i * bs:(i + 1) * bs].tobytes(), 512), dtype="<u8"))
+    assert rep["n_gpus"] == 1 and rep["bytes_out"] == out and int(rep["digest_fold"], 16) == int(fold) and rep["all_devices_agree"]
+
+
+def test_driver_devices_flag_and_rccl_totals(oracle):
+    exe = os.path.join(ROOT, "compute_war_amd", "host", "hashandcompress")
+    files = ["alice29.txt", "kennedy.xls", "ptt5"]
+    paths = [os.path.join(GOLDEN, "corpus", "canterbury", f) for f in files]
+    r = subprocess.run([exe, "-v", "-g", "true", "--devices", "1", "-c", "3", "-r", "1", "--block-size=65536", "-H", "skein512", "-C", "lz4"] + paths,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()   # RCCL announces itself on stdout: pick our lines by content
+    bs, nblocks, out = 65536, 0, 0
+    for f in files:
+        d = corpus_file(f)
+        for i in range(len(d) // bs):
+            out += len(oracle.lz4_compress(d[i * bs:(i + 1) * bs]))
+            nblocks += 1
+    assert any(ln.startswith(f"blocks={nblocks} in={nblocks * bs} out={out} ") for ln in lines)
+    assert f"devices=1 in={nblocks * bs} out={out} (ncclAllReduce over the per-device totals)" in lines
+    r = subprocess.run([exe, "--devices", "9", paths[0]], capture_output=True, text=True)
+    assert r.returncode == 2 and "out of range" in r.stderr

@@ -16,7 +16,7 @@ ap.add_argument("--bs", type=int, default=65536)
 ap.add_argument("--nb", type=int, default=262144)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--tree", default="", help="leaf,node,maxlevel: Skein tree hashing instead of sequential")
-ap.add_argument("--data", default="random", choices=["random", "zero", "text"])
+ap.add_argument("--data", default="random", choices=["random", "zero", "text", "mixed"])
 a = ap.parse_args()
 
 cw.init(0)
@@ -24,6 +24,8 @@ s = torch.cuda.current_stream().cuda_stream
 src = torch.empty(a.nb * a.bs, dtype=torch.uint8, device="cuda")
 if a.data == "random":
     cw.dev_gen_random(0xC0FFEE, 0, a.nb, a.bs, src.data_ptr(), s)
+elif a.data == "mixed":
+    cw.dev_gen_mixed(0xC0FFEE, 0, a.nb, a.bs, src.data_ptr(), s)
 elif a.data == "zero":
     src.zero_()
 else:
