@@ -694,12 +694,13 @@ void pipe_drain(ThreadCtx &c)
     (void)hipStreamSynchronize(c.s_d2h);
 }
 
-// chunk: large enough that one chunk's kernels fill a good part of the GPU (a 64 KiB Skein block is a 3 ms serial chain
-// whatever the batch), small enough that three of them pipeline; CW_HOST_CHUNK_MB overrides
+// chunk: a 64 KiB Skein block is a 3 ms serial chain whatever the batch, so a chunk of large blocks must carry enough bytes
+// for that latency (256 MiB per 3-4 ms = 70 GB/s of kernels, above the bus; 128 MiB measured 28 GB/s, kernel-latency bound)
+// yet three of them must pipeline (and fit: 3 slots x (input + slots + packed stream)); CW_HOST_CHUNK_MB overrides
 size_t pipeline_chunk(size_t bb, size_t nblocks)
 {
     static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
-    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (bb > 16384 ? (size_t)128 << 20 : (size_t)64 << 20);
+    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (bb > 16384 ? (size_t)256 << 20 : (size_t)64 << 20);
     size_t chunk = chunk_bytes / (bb ? bb : 1);
     if (chunk == 0) chunk = 1;
     if (chunk > nblocks) chunk = nblocks;

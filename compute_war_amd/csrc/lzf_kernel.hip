@@ -521,7 +521,7 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 template <bool BIG>
 __global__ void __launch_bounds__(64)
 lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst,
-                 size_t dst_stride, uint32_t *__restrict__ sizes, const uint16_t *__restrict__ links, uint32_t n2,
+                 size_t dst_stride, uint32_t *__restrict__ sizes, uint16_t *__restrict__ links, uint32_t n2,
                  uint32_t *__restrict__ counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -542,7 +542,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
         if (__builtin_amdgcn_readfirstlane(sizes[blk]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
-        const uint16_t *lk = links + blk * (size_t)n2;
+        uint16_t *lk = links + blk * (size_t)n2;
         if (BIG) {
             for (uint32_t i = lane; i < n2 / 32; i += 64) skipmap[i] = 0;
         } else {
@@ -577,22 +577,37 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             const uint32_t ntest = (uint32_t)__builtin_popcountll(__ballot(tested));
             const uint32_t v = vnext;
             // the reference the serial parser would read: first position on the link chain that was inserted
-            uint32_t cur;
+            // A skipped position stays skipped and an inserted one inserted (the parser never goes back), so the answer for
+            // a skipped position never changes: the first skipped position of a walk gets the walk's result as its link
+            // (path compression).  Without it periodic data -- a spreadsheet's records, a bitmap's rows: every period holds a
+            // same-slot position inside a long match -- walks back period by period through the whole block at every
+            // lookup, one dependent memory round trip per step for BIG blocks (kennedy.xls at 64 KiB: 0.1 GB/s).  A later
+            // walk enters at the previous walker's position and is home in three steps.  A reader that still sees the old
+            // link only walks the longer, equally valid path.
+            uint32_t cur, first_skipped = 0;
             if (BIG) {
                 cur = tested ? lnext : 0u;
                 for (;;) {
                     const bool skipped = cur && ((skipmap[cur >> 5] >> (cur & 31u)) & 1u);
-                    if (skipped) cur = lk[cur];
+                    if (skipped) {
+                        if (!first_skipped) first_skipped = cur;
+                        cur = lk[cur];
+                    }
                     if (!__ballot(skipped)) break;
                 }
+                if (first_skipped) lk[first_skipped] = (uint16_t)cur;
             } else {
                 cur = tested ? E[pos] & 0x7FFFu : 0u;
                 for (;;) {
                     const uint32_t e = cur ? E[cur] : 0u;
                     const bool skipped = (e & kSkipFlag) != 0;
-                    if (skipped) cur = e & 0x7FFFu;
+                    if (skipped) {
+                        if (!first_skipped) first_skipped = cur;
+                        cur = e & 0x7FFFu;
+                    }
                     if (!__ballot(skipped)) break;
                 }
+                if (first_skipped) E[first_skipped] = (uint16_t)(kSkipFlag | cur);
             }
             const uint32_t old = cur;
             const bool cand = tested && old > 0 && pos - old - 1 < kMaxOff;
