@@ -1368,9 +1368,238 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Lane-per-block parser for large batches of queued blocks.
+//
+// The wavefront-per-block parsers above keep the 16 KiB table in LDS, so a CU holds 8-10 blocks, and one sequence of a
+// block is a serial chain of about 2,500 cycles of instruction and LDS/memory latency (tools/parse_stamp.hip): 2,560
+// chains on the chip are 14-17 GB/s on text whatever is trimmed, and LDS capacity admits no more chains.  Here a LANE
+// owns a block and runs the serial parser as it stands (the oracle's loop, one probe per iteration), its table in global
+// memory (16 KiB per lane, zeroed by the lane when it takes a block): 64 chains per wavefront, tens of thousands per
+// chip, bound by how many random table / candidate accesses the memory system retires, not by any one chain's latency.
+// It only pays when there are that many blocks: lz4_launch uses it from kLaneMinBlocks queued blocks on.
+//
+// Every lane is in one of the states below; an iteration of the wavefront's loop runs one step of every lane:
+//   PROBE   the parser's search loop body, or the re-test right after a match (same table traffic, different follow-up)
+//   EMIT    a match was found: catch-up, literals, offset, match length; then PROBE (as a re-test) or TAIL
+//   TAIL    last literals, size; then NEXT
+//   NEXT    pull the next queued block, zero the table
+// Per iteration a lane's dependent memory chain is: its 16 bytes around ip -> table slot -> the candidate's 16 bytes.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kLaneMinBlocks = 24576; // below ~24 Ki queued 64 KiB blocks the chip is not full and the wavefront parser's 14-16 GB/s win
+enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
+
+__device__ __forceinline__ void lane_put_len(uint8_t *__restrict__ out, uint32_t &op, uint32_t extra)
+{
+    while (extra >= 255) { out[op++] = 255; extra -= 255; }
+    out[op++] = (uint8_t)extra;
+}
+
+// 4 bytes at byte offset s (4 <= s <= 12) of a 16-byte window held in (x, y, z, w)
+__device__ __forceinline__ uint32_t win_at(const uint4 &q, uint32_t s)
+{
+    return s < 8 ? __builtin_amdgcn_alignbyte(q.z, q.y, s & 3u) : s < 12 ? __builtin_amdgcn_alignbyte(q.w, q.z, s & 3u) : q.w;
+}
+
+__global__ void __launch_bounds__(64)
+lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                 uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
+                 uint16_t *__restrict__ tables, uint32_t min_blocks)
+{
+    const uint32_t qcount = counters[1];
+    if (qcount < min_blocks) return; // too few chains to fill the chip: the wavefront-per-block parser takes them all
+    uint16_t *tab = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * (1u << 13);
+    const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals; // n >= 13: a queued block had a match
+
+    uint32_t state = LS_NEXT;
+    const uint8_t *g = src;
+    uint8_t *out = dst;
+    uint32_t blk = 0, ip = 0, anchor = 0, op = 0, step = 1, nb = 64, match = 0, first_lo = 0, first_hi = 0;
+    bool retest = false;
+    // own = the 16 bytes [ip-4, ip+12), requested one iteration ahead; vcur = the 4 bytes at ip, cut out of the previous
+    // window when it reached that far (have_v), so that the table lookup never waits for the request
+    uint4 own = make_uint4(0, 0, 0, 0), cd = make_uint4(0, 0, 0, 0);
+    uint32_t vcur = 0, v2cur = 0;
+    bool have_v = false;
+    // literals of the last sequence on their way from memory: stored one iteration later (their load is then long done)
+    uint64_t pend_a = 0, pend_b = 0;
+    uint8_t *pend_dst = nullptr;
+    uint32_t pend_n = 0;
+
+    while (__ballot(state != LS_EXIT)) {
+        // everything requested during the previous iteration is waited for here, once
+        if (pend_n) { // exactly pend_n (1..16) bytes: what follows them in the slot is already written
+            uint64_t lo = pend_a;
+            uint8_t *p = pend_dst;
+            if (pend_n & 16) { __builtin_memcpy(p, &lo, 8); __builtin_memcpy(p + 8, &pend_b, 8); }
+            else {
+                if (pend_n & 8) { __builtin_memcpy(p, &lo, 8); lo = pend_b; p += 8; }
+                if (pend_n & 4) { const uint32_t t = (uint32_t)lo; __builtin_memcpy(p, &t, 4); lo >>= 32; p += 4; }
+                if (pend_n & 2) { const uint16_t t = (uint16_t)lo; __builtin_memcpy(p, &t, 2); lo >>= 16; p += 2; }
+                if (pend_n & 1) *p = (uint8_t)lo;
+            }
+            pend_n = 0;
+        }
+        if (state == LS_NEXT) {
+            const uint32_t qi = atomicAdd(&counters[0], 1u);
+            if (qi >= qcount) {
+                state = LS_EXIT;
+            } else {
+                blk = queue[qi];
+                g = src + (size_t)blk * src_stride;
+                out = dst + (size_t)blk * dst_stride;
+                uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+                for (uint32_t i = 0; i < (1u << 13) * 2 / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                first_lo = rd32(g, 0); first_hi = rd32(g, 4);
+                // tab[hash(first 4 bytes)] = 0 is what a zeroed table already says
+                ip = 1; anchor = 0; op = 0; step = 1; nb = 64; retest = false;
+                own.x = 0; own.y = rd32(g, 1); own.z = rd32(g, 5); own.w = rd32(g, 9); // no "before" at the block's start
+                have_v = false;
+                state = LS_PROBE;
+            }
+        }
+
+        if (state == LS_PROBE) {
+            const uint32_t next = ip + step;
+            if (!retest && next > mflimit + 1) {
+                state = LS_TAIL;
+            } else {
+                const uint32_t v = have_v ? vcur : own.y;
+                if (retest) { // LZ4_putPosition(ip - 2) in front of the re-test
+                    const uint32_t v2 = have_v ? v2cur : (own.x >> 16) | (own.y << 16);
+                    tab[hash13(v2)] = (uint16_t)(ip - 2);
+                }
+                const uint32_t h = hash13(v);
+                match = tab[h];
+                tab[h] = (uint16_t)ip;
+                uint32_t cat;
+                if (match >= 4) { cd = ld16g(g + match - 4); cat = cd.y; }
+                else cat = __builtin_amdgcn_alignbyte(first_hi, first_lo, match);
+                if (cat == v) {
+                    state = LS_EMIT; // (own was requested for this ip an iteration ago: it is here by now)
+                } else {
+                    uint32_t nip;
+                    if (retest) { nip = ip + 1; step = 1; nb = 64; retest = false; }
+                    else { nip = next; step = nb >> 6; nb++; }
+                    // the next position's 4 bytes, from the window if it reaches (it is the window of `ip` only if that
+                    // has arrived, which it has unless this iteration ran on vcur: then the request is still the one for ip)
+                    const uint32_t s = nip - ip + 4;
+                    have_v = s <= 12 && ip >= 4;
+                    if (have_v) vcur = win_at(own, s);
+                    ip = nip;
+                    // (ip = mflimit + 1 is never probed, the next iteration sends it to TAIL: keep its request inside the block)
+                    const uint32_t rp = ip <= mflimit ? ip : mflimit;
+                    own = ld16g(g + rp - (rp >= 4 ? 4 : 0));
+                    if (rp < 4) { own.w = own.z; own.z = own.y; own.y = own.x; own.x = 0; have_v = false; }
+                }
+            }
+        }
+
+        if (state == LS_EMIT) {
+            // own = [ip-4, ip+12) and cd = [match-4, match+12) (match >= 4), both as found by the probe
+            const uint32_t ip0 = ip;
+            const bool windows = ip >= 4 && match >= 4;
+            uint32_t nf = 0; // equal bytes behind the 4 that matched
+            bool nf_open = true;
+            if (windows) {
+                const uint64_t x = ((uint64_t)own.w << 32 | own.z) ^ ((uint64_t)cd.w << 32 | cd.z);
+                nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                nf_open = nf == 8;
+                const uint32_t lim = matchlimit - (ip0 + kMinMatch);
+                if (nf >= lim) { nf = lim; nf_open = false; }
+            }
+            // ---- catch-up over the pending literals (a re-test has none: anchor == ip) ----
+            if (!retest) {
+                if (windows) {
+                    const uint32_t room = ip - anchor < match ? ip - anchor : match;
+                    const uint32_t y = own.x ^ cd.x;
+                    uint32_t back = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+                    if (back > room) back = room;
+                    ip -= back; match -= back;
+                    if (back == 4) while (ip > anchor && match > 0 && g[ip - 1] == g[match - 1]) { ip--; match--; }
+                } else {
+                    while (ip > anchor && match > 0 && g[ip - 1] == g[match - 1]) { ip--; match--; }
+                }
+            }
+            // ---- literals: 8 or 16 bytes requested now and stored next iteration; longer runs copied here ----
+            const uint32_t lit = ip - anchor, tok = op++;
+            uint32_t token;
+            if (lit >= 15) { token = 15u << 4; lane_put_len(out, op, lit - 15); }
+            else token = lit << 4;
+            if (lit) {
+                // (8 bytes from anchor stay inside the block: anchor + 8 <= ip + 7 <= n - 5; 16 only for runs of 9 and more)
+                __builtin_memcpy(&pend_a, g + anchor, 8);
+                if (lit > 8) __builtin_memcpy(&pend_b, g + anchor + 8, 8);
+                pend_dst = out + op;
+                pend_n = lit < 16 ? lit : 16;
+                for (uint32_t k = 16; k < lit; k += 8) { // runs beyond 16 (0.3 % on text): 8 bytes at a time, the overshoot (< 8
+                    uint64_t q;                          // bytes) lands where the offset and what follows are written next
+                    __builtin_memcpy(&q, g + anchor + k, 8);
+                    __builtin_memcpy(out + op + k, &q, 8);
+                }
+            }
+            op += lit;
+            // ---- offset, match length ----
+            const uint32_t off = ip - match;
+            out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8);
+            op += 2;
+            // the bytes taken back, the 4 that matched and the nf behind them are one run: mc = (ip0 - ip) + nf (+ what memory adds)
+            uint32_t mc = ip0 - ip + nf;
+            if (nf_open) {
+                const uint32_t a = ip + kMinMatch, b = match + kMinMatch;
+                while (a + mc + 8 <= matchlimit) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, g + a + mc, 8);
+                    __builtin_memcpy(&y, g + b + mc, 8);
+                    const uint64_t d = x ^ y;
+                    if (d) { mc += (uint32_t)__builtin_ctzll(d) >> 3; break; }
+                    mc += 8;
+                }
+                if (a + mc + 8 > matchlimit) while (a + mc < matchlimit && g[a + mc] == g[b + mc]) mc++;
+            }
+            if (mc >= 15) { token += 15; lane_put_len(out, op, mc - 15); }
+            else token += mc;
+            out[tok] = (uint8_t)token;
+            ip += kMinMatch + mc;
+            anchor = ip;
+            if (ip > mflimit) {
+                state = LS_TAIL;
+            } else {
+                // the re-test's values out of the old window when the match was short enough (mend + 4 <= ip0 + 12)
+                const uint32_t s = ip - ip0 + 4;
+                have_v = windows && s <= 12;
+                if (have_v) { vcur = win_at(own, s); v2cur = win_at(own, s - 2); }
+                own = ld16g(g + ip - 4); // ip >= 5
+                retest = true;
+                state = LS_PROBE;
+            }
+        }
+
+        if (state == LS_TAIL) {
+            const uint32_t run = n - anchor;
+            if (run >= 15) { out[op++] = 15u << 4; lane_put_len(out, op, run - 15); }
+            else out[op++] = (uint8_t)(run << 4);
+            uint32_t k = 0;
+            for (; k + 16 <= run; k += 16) {
+                uint4 q;
+                __builtin_memcpy(&q, g + anchor + k, 16);
+                __builtin_memcpy(out + op + k, &q, 16);
+            }
+            for (; k < run; k++) out[op + k] = g[anchor + k];
+            op += run;
+            sizes[blk] = op;
+            state = LS_NEXT;
+        }
+    }
+}
+
 // per-stream workspace: counters[8] (parse queue head, tail; scan feed; -; second queue head, tail) + two queues
 namespace {
-struct Workspace { uint32_t *p = nullptr; size_t cap = 0; std::mutex launch; };
+struct Workspace {
+    uint32_t *p = nullptr; size_t cap = 0;
+    uint16_t *lane_tabs = nullptr; size_t lane_cap = 0; // tables of the lane-per-block parser: 16 KiB per lane
+    std::mutex launch;
+};
 std::mutex ws_lock;
 std::unordered_map<uint64_t, Workspace> ws_map; // references stay valid across inserts
 
@@ -1400,7 +1629,10 @@ hipError_t grow_workspace(Workspace &w, size_t nblocks, uint32_t **out, size_t *
 void lz4_release_workspaces()
 {
     std::lock_guard<std::mutex> g(ws_lock);
-    for (auto &kv : ws_map) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : ws_map) {
+        if (kv.second.p) (void)hipFree(kv.second.p);
+        if (kv.second.lane_tabs) (void)hipFree(kv.second.lane_tabs);
+    }
     ws_map.clear();
 }
 
@@ -1481,6 +1713,29 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const int headw = hw_env ? atoi(hw_env) : 16;
     if (use_fp) lds = kTabBytes + kFpBytes;
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
+    // Large batches of blocks that are read from global memory: the lane-per-block parser first.  It looks at the queue
+    // length on the device and leaves everything to the wavefront-per-block parser below kLaneMinBlocks queued blocks.
+    // CW_LZ4_LANES=0 switches it off, =N sets the threshold; CW_LANES_WPC = its wavefronts per CU (profiling knobs).
+    static const char *lanes_env = getenv("CW_LZ4_LANES");
+    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : kLaneMinBlocks;
+    bool lanes_used = false;
+    if (!staged && !use_fp && lane_min && nblocks >= lane_min && n >= kMFLimit + 1) {
+        static const char *lw_env = getenv("CW_LANES_WPC");
+        const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
+        size_t lgrid = (nblocks + 63) / 64;
+        if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
+        if (wsp.lane_cap < lgrid * 64) {
+            if (wsp.lane_tabs) { e = hipFree(wsp.lane_tabs); if (e != hipSuccess) return e; }
+            wsp.lane_tabs = nullptr; wsp.lane_cap = 0;
+            e = hipMalloc(reinterpret_cast<void **>(&wsp.lane_tabs), lgrid * 64 * (size_t)kTabBytes);
+            if (e != hipSuccess) return e;
+            wsp.lane_cap = lgrid * 64;
+        }
+        hipLaunchKernelGGL(lz4_lanes_kernel, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
+                           wsp.lane_tabs, lane_min);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        lanes_used = true;
+    }
     static const char *pwpc_env = getenv("CW_PARSE_WPC"); // parse wavefronts per CU (profiling knob; default: all the LDS admits)
     const size_t pwpc = pwpc_env && atoi(pwpc_env) > 0 ? (size_t)atoi(pwpc_env) : 10;
     const size_t want = 256 * (per_cu > pwpc ? pwpc : per_cu);
@@ -1510,7 +1765,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     {
         static thread_local char names[160];
-        snprintf(names, sizeof names, "%s + %s", scan_name,
+        snprintf(names, sizeof names, "%s + %s%s", scan_name, lanes_used ? "cw::lz4_lanes_kernel (large queues) / " : "",
                  cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
                  : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");
         note_kernels(0, names);

@@ -236,6 +236,33 @@ def test_alternative_lz4_parser_is_exact():
         assert "lz4_parse_kernel<false>" in " ".join(a) and "lz4_parse_fp_kernel" in " ".join(b)
 
 
+def test_lane_per_block_lz4_parser_is_exact():
+    """The lane-per-block LZ4 parser only takes over from 24 Ki queued blocks on; CW_LZ4_LANES=1 (threshold 1, read once per
+    process) sends every queued block through it: corpus blocks at 8 / 16 / 64 KiB, runs, a block with one long tail."""
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, compute_war_amd as cw\n"
+        "from conftest import corpus_file\n"
+        "cw.init(0)\n"
+        "rng = np.random.default_rng(5)\n"
+        "sparse = rng.integers(0, 256, 3 * 65536, dtype=np.uint8); sparse[1000:1016] = sparse[200:216]; sparse[70000:70300] = 7\n"
+        "data = corpus_file('lcet10.txt')[:6*65536] + bytes(65536) + corpus_file('kennedy.xls')[:5*65536] + corpus_file('ptt5')[:3*65536] + corpus_file('sum')[:32768] * 2 + sparse.tobytes()\n"
+        "for bs in (8192, 16384, 65536):\n"
+        "    sizes, payload = cw.compress_blocks('lz4', data, bs)\n"
+        "    h = hashlib.sha256(sizes.tobytes())\n"
+        "    for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
+        "    print(bs, int(sizes.sum()), h.hexdigest(), cw.profile_kernels()['codec'])\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({}, {"CW_LZ4_LANES": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
+    assert len(outs[0]) == 3
+    for a, b, c in zip(*outs):
+        assert a[:3] == b[:3] == c[:3]
+        assert "lz4_lanes_kernel" not in " ".join(a) and "lz4_lanes_kernel" in " ".join(b)
+
+
 def test_devices_and_contexts(cw):
     assert cw.device_count() >= 1 and cw.get_device() == 0
     cw.set_device(0)
