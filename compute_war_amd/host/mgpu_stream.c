@@ -194,7 +194,15 @@ int main(int argc, char **argv)
            n_dev, blocks_per_gpu, block_size, steps, mixed ? "mixed" : "random", in_bytes / secs / 1e9, secs / steps * 1e3,
            (unsigned long long)totals[0], (double)total_blocks * (double)block_size / (double)totals[0], (unsigned long long)ranks[0].fold,
            agree ? "true" : "false");
+    for (int g = 0; g < n_dev; g++) {
+        (void)cw_set_device(devs[g]);
+        cw_dev_free(ranks[g].d_src); cw_dev_free(ranks[g].d_dst); cw_dev_free(ranks[g].d_sizes);
+        cw_dev_free(ranks[g].d_digests); cw_dev_free(ranks[g].d_all); cw_dev_free(ranks[g].d_totals);
+    }
     cw_mgpu_destroy(mg);
     cw_shutdown();
+    pthread_barrier_destroy(&bar);
+    free(tid);
+    free(ranks);
     return agree ? 0 : 3;
 }
