@@ -540,6 +540,18 @@ int cw_dev_synchronize(void)
     return CW_OK;
 }
 
+#ifdef CW_CLOCK_STAMP
+// diagnostic build only (tools/clock_probe.py): the in-kernel clock stamps of the last launches
+int cw_debug_clock_read(int which, unsigned long long *out)
+{
+    int rc = ensure_init();
+    if (rc != CW_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(which == 0 ? cw::skein_clock_read(out) : cw::lz4_clock_read(out));
+    return CW_OK;
+}
+#endif
+
 void cw_profile_enable(int on) { t_prof_on = on != 0; }
 
 int cw_profile_read(double ms_sum[3], unsigned count[3], int reset)

@@ -12,6 +12,36 @@
 
 namespace cw {
 
+// Diagnostic build only (-DCW_CLOCK_STAMP, tools/clock_probe.py): the clock a kernel actually runs at.  Lane 0 of a workgroup
+// reads s_memtime (shader cycles) and s_memrealtime (a constant 100 MHz counter) when the workgroup starts and when it ends;
+// the four values go to a buffer nothing else reads, and the host takes, per workgroup, d(memtime) / d(memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6).  In the product build no stamp executes.
+#ifdef CW_CLOCK_STAMP
+constexpr unsigned kClockSlots = 1024;
+struct ClockScope {
+    unsigned long long m0 = 0, r0 = 0;
+    unsigned long long *rec;
+    bool on;
+    __device__ ClockScope(unsigned long long *buf, unsigned wg) : rec(buf + 4 * (wg % kClockSlots)), on(threadIdx.x == 0)
+    {
+        if (on) { m0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ ~ClockScope()
+    {
+        if (on) {
+            const unsigned long long m1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            rec[0] = m0; rec[1] = r0; rec[2] = m1; rec[3] = r1;
+        }
+    }
+};
+#define CW_CLOCK_SCOPE(buf) ClockScope clock_scope_(buf, blockIdx.x)
+// which: 0 = the Skein slice kernel, 1 = the LZ4 span scan; out = kClockSlots x {m0, r0, m1, r1}
+hipError_t skein_clock_read(unsigned long long *out);
+hipError_t lz4_clock_read(unsigned long long *out);
+#else
+#define CW_CLOCK_SCOPE(buf) do { } while (0)
+#endif
+
 // Key of the per-(device, stream) scratch the launch sequences keep (the NULL stream exists once per device).  Every
 // entry also holds a launch mutex: a sequence of launches that shares scratch -- memset counters, scan, parse, redo; the
 // chained slices of one hash -- is queued under it, so that two host threads using the same stream cannot interleave

@@ -456,11 +456,17 @@ lz4_scan_stream_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_s
 // Step i: store chunk i-1 (speculatively, as before), load chunk i+2 into the registers that frees, finish the
 // previous block if chunk i starts a new one, stage chunk i in the LDS ring, probe the positions below it.
 // ---------------------------------------------------------------------------------------------------
+#ifdef CW_CLOCK_STAMP
+__device__ unsigned long long g_clock_scan[4 * kClockSlots];
+hipError_t lz4_clock_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_scan), sizeof g_clock_scan); }
+#endif
+
 __global__ void __launch_bounds__(64)
 lz4_scan_span_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint32_t nspans, uint8_t *__restrict__ dst,
                      size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t nprobes, uint32_t *__restrict__ queue,
                      uint32_t *__restrict__ counters, uint32_t lg)
 {
+    CW_CLOCK_SCOPE(g_clock_scan);
     __shared__ __attribute__((aligned(16))) uint32_t tab[1u << 13];
     __shared__ __attribute__((aligned(16))) uint32_t ring32[kRing / 4];
     volatile uint32_t *mailbox = ring32; // free between two spans
@@ -1719,7 +1725,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     static const char *lanes_env = getenv("CW_LZ4_LANES");
     const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : kLaneMinBlocks;
     bool lanes_used = false;
-    if (!staged && !use_fp && lane_min && nblocks >= lane_min && n >= kMFLimit + 1) {
+    static const char *small_env = getenv("CW_LANES_SMALL"); // experiment: lanes also for blocks the LDS-staged parser takes
+    const bool lanes_small = small_env && small_env[0] == '1' && n >= 64;
+    if ((!staged || lanes_small) && !use_fp && lane_min && nblocks >= lane_min && n >= kMFLimit + 1) {
         static const char *lw_env = getenv("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
         size_t lgrid = (nblocks + 63) / 64;

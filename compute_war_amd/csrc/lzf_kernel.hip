@@ -720,8 +720,148 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Lane-per-block parser for large batches of blocks that do not fit the LDS-resident scheme (> 4 KiB): the counterpart
+// of lz4_lanes_kernel (lz4_kernel.hip has the reasoning).  A lane runs liblzf's loop as it stands -- one position per
+// iteration: hash the next three bytes, exchange the table slot, test the reference, emit a literal or a match -- with its
+// 65,536 x u16 table in global memory (128 KiB per lane, zeroed by the lane when it takes a block).  No links, no skip
+// flags, no lane-order assumption: the parse is the serial one.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kLzfLaneMinBlocks = 24576;
+
+// 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
+__device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32_t n)
+{
+    const uint32_t q = ip + 4 <= n ? ip : n - 4;
+    return lz::rd32(g, q) >> ((ip - q) * 8);
+}
+
+__global__ void __launch_bounds__(64)
+lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst, size_t dst_stride,
+                 uint32_t *__restrict__ sizes, uint16_t *__restrict__ tables, uint32_t *__restrict__ counter)
+{
+    uint16_t *tab = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLzfSlots;
+    const uint32_t cap = n - 1; // out_len of the reference's call (n >= 16 here)
+    enum : uint32_t { NEXT = 0, STEP = 1, TAIL = 2, EXIT = 3 };
+    uint32_t state = NEXT, ip = 0, op = 0, lit = 0, v = 0;
+    size_t blk = 0;
+    const uint8_t *g = src;
+    uint8_t *out = dst;
+    bool fail = false;
+
+    while (__ballot(state != EXIT)) {
+        if (state == NEXT) {
+            blk = atomicAdd(counter, 1u);
+            if (blk >= nblocks) {
+                state = EXIT;
+            } else {
+                g = src + blk * src_stride;
+                out = dst + blk * dst_stride;
+                uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+                for (uint32_t i = 0; i < kLzfTabBytes / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                ip = 0; op = 1; lit = 0; fail = false; // op = 1: the first literal run's control byte is reserved
+                v = lzf_rd(g, 0, n);
+                state = STEP;
+            }
+        }
+
+        if (state == STEP) {
+            // v = the 4 bytes at ip (requested an iteration ago)
+            const uint32_t b0 = v & 0xFFu, b1 = (v >> 8) & 0xFFu, b2 = (v >> 16) & 0xFFu;
+            const uint32_t slot = lzf_slot(b0, b1, b2);
+            const uint32_t ref = tab[slot];
+            tab[slot] = (uint16_t)ip;
+            bool is_match = false;
+            if (ref > 0 && ip - ref - 1 < kMaxOff) is_match = ((lz::rd32(g, ref) ^ v) & 0xFFFFFFu) == 0; // ref + 4 <= ip + 3 <= n
+            if (is_match) {
+                uint32_t maxlen = n - ip - 2;
+                if (maxlen > kMaxRef) maxlen = kMaxRef;
+                if (op + 4 >= cap && op - (lit == 0) + 4 >= cap) {
+                    fail = true; state = TAIL;
+                } else {
+                    if (lit) out[op - lit - 1] = (uint8_t)(lit - 1);
+                    else op -= 1;
+                    // equal bytes from index 3 on, as far as the reference's loops can look
+                    const uint32_t room = (n - ip < kMaxRef + 2 ? n - ip : kMaxRef + 2) - 3;
+                    uint32_t eq = 0;
+                    while (eq + 8 <= room) {
+                        uint64_t x, y;
+                        __builtin_memcpy(&x, g + ref + 3 + eq, 8);
+                        __builtin_memcpy(&y, g + ip + 3 + eq, 8);
+                        const uint64_t d = x ^ y;
+                        if (d) { eq += (uint32_t)__builtin_ctzll(d) >> 3; break; }
+                        eq += 8;
+                    }
+                    if (eq + 8 > room) while (eq < room && g[ref + 3 + eq] == g[ip + 3 + eq]) eq++;
+                    uint32_t len;
+                    if (maxlen > 16) { // 16 unrolled compares without a bound, then the bounded loop
+                        if (eq < 16) len = 3 + eq;
+                        else { len = 3 + eq < maxlen ? 3 + eq : maxlen; if (len < 19) len = 19; }
+                    } else {
+                        len = 3 + eq < maxlen ? 3 + eq : maxlen;
+                        if (len < 3) len = 3;
+                    }
+                    const uint32_t off = ip - ref - 1, l2 = len - 2;
+                    if (l2 < 7) {
+                        out[op] = (uint8_t)((off >> 8) + (l2 << 5));
+                        out[op + 1] = (uint8_t)off;
+                        op += 2;
+                    } else {
+                        out[op] = (uint8_t)((off >> 8) + (7u << 5));
+                        out[op + 1] = (uint8_t)(l2 - 7);
+                        out[op + 2] = (uint8_t)off;
+                        op += 3;
+                    }
+                    lit = 0; op += 1;
+                    ip += len;
+                    if (ip + 2 >= n) {
+                        state = TAIL;
+                    } else { // VERY_FAST: only the last two positions of the match are inserted
+                        const uint32_t w = lz::rd32(g, ip - 2); // bytes ip-2 .. ip+1
+                        tab[lzf_slot(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu)] = (uint16_t)(ip - 2);
+                        tab[lzf_slot((w >> 8) & 0xFFu, (w >> 16) & 0xFFu, w >> 24)] = (uint16_t)(ip - 1);
+                        v = lzf_rd(g, ip, n);
+                    }
+                }
+            } else {
+                if (op >= cap) {
+                    fail = true; state = TAIL;
+                } else {
+                    lit++;
+                    out[op++] = (uint8_t)b0;
+                    if (lit == kMaxLit) { out[op - lit - 1] = (uint8_t)(kMaxLit - 1); lit = 0; op++; }
+                    ip++;
+                    if (ip + 2 < n) v = (v >> 8) | ((uint32_t)(ip + 3 < n ? g[ip + 3] : 0u) << 24);
+                    else state = TAIL;
+                }
+            }
+        }
+
+        if (state == TAIL) {
+            if (!fail) {
+                if (op + 3 > cap) {
+                    fail = true;
+                } else {
+                    while (ip < n) {
+                        lit++;
+                        out[op++] = g[ip++];
+                        if (lit == kMaxLit) { out[op - lit - 1] = (uint8_t)(kMaxLit - 1); lit = 0; op++; }
+                    }
+                    if (lit) out[op - lit - 1] = (uint8_t)(lit - 1);
+                    else op -= 1;
+                }
+            }
+            sizes[blk] = fail ? 0u : op;
+            state = NEXT;
+        }
+    }
+}
+
 namespace {
-struct LinkSpace { uint16_t *p = nullptr; size_t cap = 0; uint32_t *counter = nullptr; };
+struct LinkSpace {
+    uint16_t *p = nullptr; size_t cap = 0; uint32_t *counter = nullptr;
+    uint16_t *lane_tabs = nullptr; size_t lane_cap = 0; // tables of the lane-per-block parser: 128 KiB per lane
+};
 struct LinkEntry { LinkSpace s; std::mutex launch; };
 std::mutex link_lock;
 std::unordered_map<uint64_t, LinkEntry> link_map; // references stay valid across inserts
@@ -733,6 +873,7 @@ void lzf_release_workspaces()
     for (auto &kv : link_map) {
         if (kv.second.s.p) (void)hipFree(kv.second.s.p);
         if (kv.second.s.counter) (void)hipFree(kv.second.s.counter);
+        if (kv.second.s.lane_tabs) (void)hipFree(kv.second.s.lane_tabs);
     }
     link_map.clear();
 }
@@ -779,6 +920,32 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             entry = &link_map[ws_key(stream)];
         }
         std::lock_guard<std::mutex> sequence(entry->launch); // the link array and the counter are shared by the launches below
+        // large batches of large blocks: the lane-per-block parser (CW_LZF_LANES=0 off, =N threshold; CW_LANES_WPC wavefronts per CU)
+        static const char *lanes_env = getenv("CW_LZF_LANES");
+        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : kLzfLaneMinBlocks;
+        static const char *small_env = getenv("CW_LANES_SMALL"); // experiment: lanes also for blocks that fit the LDS scheme
+        const bool lanes_small = small_env && small_env[0] == '1';
+        if ((big || lanes_small) && lane_min && nblocks >= lane_min) {
+            static const char *lw_env = getenv("CW_LANES_WPC");
+            const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 4;
+            size_t lgrid = (nblocks + 63) / 64;
+            if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
+            LinkSpace &w = entry->s;
+            hipError_t e;
+            if (w.lane_cap < lgrid * 64) {
+                if (w.lane_tabs) { e = hipFree(w.lane_tabs); if (e != hipSuccess) return e; }
+                w.lane_tabs = nullptr; w.lane_cap = 0;
+                e = hipMalloc(reinterpret_cast<void **>(&w.lane_tabs), lgrid * 64 * (size_t)kLzfTabBytes);
+                if (e != hipSuccess) return e;
+                w.lane_cap = lgrid * 64;
+            }
+            if (!w.counter && (e = hipMalloc(reinterpret_cast<void **>(&w.counter), 64)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(w.counter, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(lzf_lanes_kernel, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride, sizes,
+                               w.lane_tabs, w.counter);
+            note_kernels(0, "cw::lzf_lanes_kernel");
+            return hipGetLastError();
+        }
         {
             LinkSpace &w = entry->s;
             if (w.cap < chunk * n2) {

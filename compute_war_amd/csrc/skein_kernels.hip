@@ -380,11 +380,17 @@ skein_lines_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t s
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kSkeinSlices = 8;
 
+#ifdef CW_CLOCK_STAMP
+__device__ unsigned long long g_clock_skein[4 * kClockSlots];
+hipError_t skein_clock_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_skein), sizeof g_clock_skein); }
+#endif
+
 template <int NW, bool ALIGNED16>
 __global__ void __launch_bounds__(CW_SKEIN_THREADS)
 skein_slice_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t src_stride, size_t nblocks, SkeinIV iv,
                    uint8_t *__restrict__ digests, unsigned digest_bytes, uint64_t *__restrict__ state, size_t s_begin, size_t s_end)
 {
+    CW_CLOCK_SCOPE(g_clock_skein);
     constexpr unsigned BB = NW * 8, SPL = 128 / BB, HS = SPL / 2;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nblocks) return;

@@ -263,6 +263,33 @@ def test_lane_per_block_lz4_parser_is_exact():
         assert "lz4_lanes_kernel" not in " ".join(a) and "lz4_lanes_kernel" in " ".join(b)
 
 
+def test_lane_per_block_lzf_parser_is_exact():
+    """CW_LZF_LANES=1 sends every block > 4 KiB through the lane-per-block LZF parser (normally only from 24 Ki blocks on):
+    corpus blocks, runs, noise that does not fit (returns 0), at 8 / 16 / 64 KiB."""
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, compute_war_amd as cw\n"
+        "from conftest import corpus_file\n"
+        "cw.init(0)\n"
+        "rng = np.random.default_rng(5)\n"
+        "noise = rng.integers(0, 256, 2 * 65536, dtype=np.uint8).tobytes()\n"
+        "data = corpus_file('lcet10.txt')[:6*65536] + bytes(65536) + corpus_file('kennedy.xls')[:5*65536] + corpus_file('ptt5')[:3*65536] + noise + corpus_file('sum')[:32768] * 2\n"
+        "for bs in (8192, 16384, 65536):\n"
+        "    sizes, payload = cw.compress_blocks('lzf', data, bs)\n"
+        "    h = hashlib.sha256(sizes.tobytes())\n"
+        "    for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
+        "    print(bs, int(sizes.sum()), int((sizes == 0).sum()), h.hexdigest(), cw.profile_kernels()['codec'])\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({}, {"CW_LZF_LANES": "1"}, {"CW_LZF_LANES": "1", "CW_LANES_WPC": "1"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
+    assert len(outs[0]) == 3
+    for a, b, c in zip(*outs):
+        assert a[:4] == b[:4] == c[:4] and int(a[2]) > 0
+        assert "lzf_lanes_kernel" not in " ".join(a) and "lzf_lanes_kernel" in " ".join(b)
+
+
 def test_devices_and_contexts(cw):
     assert cw.device_count() >= 1 and cw.get_device() == 0
     cw.set_device(0)
