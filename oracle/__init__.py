@@ -42,6 +42,7 @@ def lib() -> C.CDLL:
         L.cw_oracle_skein_iv.argtypes = [C.c_int, C.c_uint, u8p]
         L.cw_oracle_skein_tree.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint, u8p]
         L.cw_oracle_skein_tree.restype = C.c_int
+        L.cw_oracle_threefish_trace.argtypes = [C.c_int, u8p, u8p, u8p, u8p]
         L.cw_oracle_sha256.argtypes = [u8p, C.c_size_t, u8p]
         for f in (L.cw_oracle_lz4_compress, L.cw_oracle_lzf_compress):
             f.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t]
@@ -99,6 +100,16 @@ def skein_iv(state_words: int, hash_bits: int) -> np.ndarray:
     iv = np.zeros(state_words, dtype=np.uint64)
     lib().cw_oracle_skein_iv(state_words, hash_bits, _ptr(iv))
     return iv
+
+
+def threefish_trace(state_words: int, key, tweak, block: bytes):
+    """(states [1 + 72 + 18, state_words] uint64 in execution order, chaining output [state_words])."""
+    k = np.array(key, dtype=np.uint64).copy()
+    t = np.array(tweak, dtype=np.uint64)
+    b = _buf(block)
+    tr = np.zeros((91, state_words), dtype=np.uint64)
+    lib().cw_oracle_threefish_trace(state_words, _ptr(k), _ptr(t), _ptr(b), _ptr(tr))
+    return tr, k
 
 
 def sha256(data) -> bytes:

@@ -39,6 +39,11 @@ void cw_oracle_skein_iv(int state_words, unsigned hash_bits, uint64_t *iv);
 int cw_oracle_skein_tree(int state_words, const uint8_t *msg, size_t len, unsigned hash_bits, unsigned leaf, unsigned node,
                          unsigned max_level, uint8_t *out);
 
+/* debug aid (the reference's SKEIN_DEBUG callouts, skein.h:246-254): one Threefish call + feed-forward with the state after
+ * the initial key injection, after each of the 72 rounds and after each of the 18 later key injections, in execution
+ * order -- (1 + 72 + 18) * state_words words; checked against KAT_MCT/skein_golden_kat_short_internals.txt */
+void cw_oracle_threefish_trace(int state_words, uint64_t *key, const uint64_t *tweak, const uint8_t *block, uint64_t *trace);
+
 /* ---- SHA-256 (FIPS 180-4) ---------------------------------------------- */
 void cw_oracle_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
 

@@ -49,7 +49,10 @@ static uint64_t load_le64(const uint8_t *p)
  * One UBI step: chain <- Threefish_{chain, tweak}(block) XOR block.
  * nw = 4 or 8 state words, 72 rounds, a subkey every 4 rounds.
  */
-static void ubi_block(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const uint8_t *block)
+/* trace (optional, the reference's SKEIN_DEBUG callouts skein.h:246-254 / skein_debug.h:13-44): the state after the
+ * initial key injection, after every round and after every later key injection, in execution order: 1 + 72 + 18
+ * records of nw words -- what KAT_MCT/skein_golden_kat_short_internals.txt lists per Threefish call */
+static void ubi_block_trace(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const uint8_t *block, uint64_t *trace)
 {
     uint64_t ks[9], ts[3], w[8], v[8], tmp[8];
     int i, d, s;
@@ -66,6 +69,7 @@ static void ubi_block(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const u
             v[nw - 3] += ts[s % 3];
             v[nw - 2] += ts[(s + 1) % 3];
             v[nw - 1] += (uint64_t)s;
+            if (trace) { memcpy(trace, v, sizeof(uint64_t) * (size_t)nw); trace += nw; }
         }
         for (i = 0; i < nw / 2; i++) {
             unsigned r = (nw == 4) ? ROT4[d & 7][i] : ROT8[d & 7][i];
@@ -74,14 +78,28 @@ static void ubi_block(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const u
         }
         for (i = 0; i < nw; i++) tmp[i] = v[(nw == 4) ? PERM4[i] : PERM8[i]];
         memcpy(v, tmp, sizeof(uint64_t) * (size_t)nw);
+        if (trace) { memcpy(trace, v, sizeof(uint64_t) * (size_t)nw); trace += nw; }
     }
     s = 18;
     for (i = 0; i < nw; i++) v[i] += ks[(s + i) % (nw + 1)];
     v[nw - 3] += ts[s % 3];
     v[nw - 2] += ts[(s + 1) % 3];
     v[nw - 1] += (uint64_t)s;
+    if (trace) memcpy(trace, v, sizeof(uint64_t) * (size_t)nw);
 
     for (i = 0; i < nw; i++) chain[i] = v[i] ^ w[i];
+}
+
+static void ubi_block(int nw, uint64_t *chain, uint64_t t0, uint64_t t1, const uint8_t *block)
+{
+    ubi_block_trace(nw, chain, t0, t1, block, NULL);
+}
+
+/* One Threefish call + feed-forward with its round-by-round state (debug aid; nw = 4 or 8).  key: nw words (updated to the
+ * chaining output), tweak: 2 words, block: nw * 8 bytes, trace: (1 + 72 + 18) * nw words. */
+void cw_oracle_threefish_trace(int nw, uint64_t *key, const uint64_t *tweak, const uint8_t *block, uint64_t *trace)
+{
+    ubi_block_trace(nw, key, tweak[0], tweak[1], block, trace);
 }
 
 static void skein_iv_tree(int nw, unsigned hash_bits, uint64_t tree_info, uint64_t *iv)

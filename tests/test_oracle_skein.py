@@ -88,3 +88,33 @@ def test_tree_mode_degenerate_cases(oracle):
     assert len(oracle.skein_tree(256, b"", 128, 1, 1, 255)) == 16
     with pytest.raises(ValueError):
         oracle.skein_tree(512, msg, 512, 0, 1, 2)
+
+
+def test_threefish_round_by_round_against_reference_internals(oracle):
+    """the reference ships a round-by-round dump of its SKEIN_DEBUG build
+    (KAT_MCT/skein_golden_kat_short_internals.txt, callouts skein.h:246-254); the oracle's Threefish reproduces every state of
+    the file's Threefish-256 and -512 call records (tests/golden/skein_internals.json, extracted by tools/make_golden.py
+    --internals): after the initial key injection, after each of the 72 rounds, after each of the 18 key injections.
+    The oracle is written in the textbook form (MIX, then move the words); the reference's code renames operands instead and
+    dumps the words where it holds them, which inside a group of four rounds lags the textbook order by the remaining word
+    permutations -- the only mapping applied here."""
+    import numpy as np
+    perm = {4: [0, 3, 2, 1], 8: [2, 1, 4, 7, 6, 5, 0, 3]}
+    calls = load_golden("skein_internals.json")["calls"]
+    assert {c["state_words"] for c in calls} == {4, 8} and len(calls) >= 4
+    for c in calls:
+        nw = c["state_words"]
+        block = np.array(c["block_words"], dtype="<u8").tobytes()
+        trace, chain = oracle.threefish_trace(nw, c["key"], c["tweak"], block)
+        exp = np.array(c["states"], dtype=np.uint64)
+        row = 0
+        for rec in range(91):
+            # record 0: initial injection; then groups of (4 rounds, 1 injection)
+            j = 0 if rec == 0 else (rec - 1) % 5 + 1          # 1..4 = round within its group, 5 = the injection behind it
+            k = (4 - j) % 4 if j in (1, 2, 3) else 0           # word permutations the reference's operand order is behind by
+            idx = list(range(nw))
+            for _ in range(k):
+                idx = [idx[p] for p in perm[nw]]
+            assert np.array_equal(exp[rec], trace[rec][idx]), (nw, rec)
+            row += 1
+        assert np.array_equal(chain, trace[90] ^ np.array(c["block_words"], dtype=np.uint64))   # feed-forward
