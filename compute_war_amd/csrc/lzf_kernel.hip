@@ -15,6 +15,8 @@
 // is exact too.
 //
 // Kernels (DESIGN.md 4.4 has the measurements):
+//   > 4 KiB, >= 24 Ki blocks:  lzf_lanes_kernel (one block per LANE, liblzf's loop as it stands, 128 KiB table per lane in
+//                      global memory);
 //   blocks <= 16 KiB:  lzf_links_kernel (per-position "previous position with my slot", 128 KiB table, throughput
 //                      bound) + lzf_chain_kernel (parse on link chains + skip flags: 12.3 KiB of LDS per 4 KiB block,
 //                      13 blocks per CU, no table writes);
