@@ -706,13 +706,17 @@ void pipe_drain(ThreadCtx &c)
     (void)hipStreamSynchronize(c.s_d2h);
 }
 
-// chunk: a 64 KiB Skein block is a 3 ms serial chain whatever the batch, so a chunk of large blocks must carry enough bytes
-// for that latency (256 MiB per 3-4 ms = 70 GB/s of kernels, above the bus; 128 MiB measured 28 GB/s, kernel-latency bound)
-// yet three of them must pipeline (and fit: 3 slots x (input + slots + packed stream)); CW_HOST_CHUNK_MB overrides
+// chunk: a chunk's kernels cost 8-10 ms almost whatever its size (a 64 KiB Skein block is a serial chain of 1,025 steps, 8 hash
+// launches of ~0.5 ms each even for a few thousand blocks, plus scan / parse / pack launches), and the kernels of successive
+// chunks do not overlap each other in practice (rocprofv3 timeline; more hardware queues -- GPU_MAX_HW_QUEUES -- did not
+// change that and made 4 KiB blocks 7x slower).  So a chunk of large blocks must carry enough bytes for that time to hide
+// behind its own host->device copy: 64 / 128 / 256 / 512 MiB measured 21.7 / 27.8 / 28.0 / 45.7 GB/s on random 64 KiB blocks
+// (the last is the link's duplex rate).  Three slots x (input + slots + packed stream) = 4.6 GiB of device memory per calling
+// thread at 512 MiB.  CW_HOST_CHUNK_MB overrides.
 size_t pipeline_chunk(size_t bb, size_t nblocks)
 {
     static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
-    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (bb > 16384 ? (size_t)256 << 20 : (size_t)64 << 20);
+    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (bb > 16384 ? (size_t)512 << 20 : (size_t)64 << 20);
     size_t chunk = chunk_bytes / (bb ? bb : 1);
     if (chunk == 0) chunk = 1;
     if (chunk > nblocks) chunk = nblocks;
