@@ -290,6 +290,50 @@ def test_lane_per_block_lzf_parser_is_exact():
         assert "lzf_lanes_kernel" not in " ".join(a) and "lzf_lanes_kernel" in " ".join(b)
 
 
+def test_lane_parsers_odd_sizes_strides_and_alignment(oracle):
+    """Both lane-per-block parsers through the device API with block sizes that are not multiples of anything, a source
+    stride larger than the block and a base that is not aligned -- the byte-granular loads at the ends of a block must
+    stay inside it (the last block ends where the buffer ends)."""
+    prog = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, torch, hashlib, compute_war_amd as cw\n"
+        "from conftest import corpus_file\n"
+        "cw.init(0)\n"
+        "s = torch.cuda.current_stream().cuda_stream\n"
+        "text = corpus_file('fields.c') + corpus_file('cp.html') + corpus_file('sum') + corpus_file('ptt5')[:90000]\n"
+        "for bs, nb, sstride, shift in ((5001, 40, 5001, 3), (12345, 19, 12345 + 7, 1), (65535, 5, 65535, 0), (4100, 70, 4100, 2)):\n"
+        "    raw = np.frombuffer((text * (sstride * nb // len(text) + 2))[:sstride * (nb - 1) + bs + shift], dtype=np.uint8).copy()\n"
+        "    raw[::5] ^= np.arange(len(raw[::5]), dtype=np.uint8)\n"
+        "    dev = torch.from_numpy(raw).cuda()\n"
+        "    base = dev.data_ptr() + shift\n"
+        "    for comp in ('lz4', 'lzf'):\n"
+        "        dstride = cw.compress_bound(comp, bs) + 3\n"
+        "        dst = torch.zeros(nb * dstride + 64, dtype=torch.uint8, device='cuda')\n"
+        "        sizes = torch.zeros(nb, dtype=torch.int32, device='cuda')\n"
+        "        cw.dev_compress(comp, base, bs, nb, dst.data_ptr() + 1, dstride, sizes.data_ptr(), s, src_stride=sstride)\n"
+        "        torch.cuda.synchronize()\n"
+        "        hz, hd = sizes.cpu().numpy(), dst.cpu().numpy()\n"
+        "        h = hashlib.sha256(hz.tobytes())\n"
+        "        for i in range(nb): h.update(hd[1 + i * dstride: 1 + i * dstride + hz[i]].tobytes())\n"
+        "        print(bs, comp, int(hz.sum()), h.hexdigest(), cw.profile_kernels()['codec'])\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({"CW_LZ4_LANES": "0", "CW_LZF_LANES": "0"}, {"CW_LZ4_LANES": "1", "CW_LZF_LANES": "1"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
+    assert len(outs[0]) == 8
+    for a, b in zip(*outs):
+        assert a[:4] == b[:4], (a, b)
+        assert "lanes_kernel" not in " ".join(a) and "lanes_kernel" in " ".join(b)
+    # and the reference run itself against the oracle, for one of the shapes
+    text = corpus_file("fields.c") + corpus_file("cp.html") + corpus_file("sum") + corpus_file("ptt5")[:90000]
+    bs, nb, sstride, shift = 5001, 40, 5001, 3
+    raw = np.frombuffer((text * (sstride * nb // len(text) + 2))[:sstride * (nb - 1) + bs + shift], dtype=np.uint8).copy()
+    raw[::5] ^= np.arange(len(raw[::5]), dtype=np.uint8)
+    tot = sum(len(oracle.lz4_compress(raw[shift + i * sstride: shift + i * sstride + bs].tobytes())) for i in range(nb))
+    assert int(outs[0][0][2]) == tot
+
+
 def test_devices_and_contexts(cw):
     assert cw.device_count() >= 1 and cw.get_device() == 0
     cw.set_device(0)
