@@ -1396,6 +1396,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // Per iteration a lane's dependent memory chain is: its 16 bytes around ip -> table slot -> the candidate's 16 bytes.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kLaneMinBlocks = 24576; // below ~24 Ki queued 64 KiB blocks the chip is not full and the wavefront parser's 14-16 GB/s win
+constexpr uint32_t kLaneMinSmall = 98304;  // LDS-staged blocks: lanes beside the LDS-resident parser from 96 Ki blocks on
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
 __device__ __forceinline__ void lane_put_len(uint8_t *__restrict__ out, uint32_t &op, uint32_t extra)
@@ -1410,15 +1411,28 @@ __device__ __forceinline__ uint32_t win_at(const uint4 &q, uint32_t s)
     return s < 8 ? __builtin_amdgcn_alignbyte(q.z, q.y, s & 3u) : s < 12 ? __builtin_amdgcn_alignbyte(q.w, q.z, s & 3u) : q.w;
 }
 
+// TAGGED (blocks <= 4 KiB): a table entry is epoch:4 | position:12; an entry of another epoch reads as empty (= position 0,
+// as in the parser's zeroed table) and the table is zeroed once per 15 blocks instead of per block.
+template <bool TAGGED>
 __global__ void __launch_bounds__(64)
 lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                  uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
-                 uint16_t *__restrict__ tables, uint32_t min_blocks)
+                 uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve)
 {
     const uint32_t qcount = counters[1];
     if (qcount < min_blocks) return; // too few chains to fill the chip: the wavefront-per-block parser takes them all
+    // reserve > 0: the wavefront-per-block parser runs BESIDE this kernel on another stream, pulling from the same queue (it
+    // is bound by LDS capacity and its own latency, this kernel by random memory accesses: the rates add).  A block takes a lane
+    // ~100 ms and a wavefront ~10 ms, so the lanes stop pulling while `reserve` blocks are left: the wavefronts finish those in
+    // about the time the lanes need for the blocks they hold.
     uint16_t *tab = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * (1u << 13);
     const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals; // n >= 13: a queued block had a match
+    uint32_t epoch = 15; // TAGGED: forces a clean table before the first block
+    auto tab_get = [&](uint32_t h) -> uint32_t {
+        const uint32_t e = tab[h];
+        return TAGGED ? ((e >> 12) == epoch ? e & 0xFFFu : 0u) : e;
+    };
+    auto tab_put = [&](uint32_t h, uint32_t pos) { tab[h] = (uint16_t)(TAGGED ? (epoch << 12) | pos : pos); };
 
     uint32_t state = LS_NEXT;
     const uint8_t *g = src;
@@ -1450,17 +1464,22 @@ lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             pend_n = 0;
         }
         if (state == LS_NEXT) {
-            const uint32_t qi = atomicAdd(&counters[0], 1u);
+            uint32_t qi = qcount;
+            if (!reserve || __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + reserve < qcount)
+                qi = atomicAdd(&counters[0], 1u);
             if (qi >= qcount) {
                 state = LS_EXIT;
             } else {
                 blk = queue[qi];
                 g = src + (size_t)blk * src_stride;
                 out = dst + (size_t)blk * dst_stride;
-                uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-                for (uint32_t i = 0; i < (1u << 13) * 2 / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                if (!TAGGED || ++epoch == 16) {
+                    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+                    for (uint32_t i = 0; i < (1u << 13) * 2 / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                    epoch = 1;
+                }
                 first_lo = rd32(g, 0); first_hi = rd32(g, 4);
-                // tab[hash(first 4 bytes)] = 0 is what a zeroed table already says
+                // tab[hash(first 4 bytes)] = 0 is what an empty table already says
                 ip = 1; anchor = 0; op = 0; step = 1; nb = 64; retest = false;
                 own.x = 0; own.y = rd32(g, 1); own.z = rd32(g, 5); own.w = rd32(g, 9); // no "before" at the block's start
                 have_v = false;
@@ -1476,11 +1495,11 @@ lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 const uint32_t v = have_v ? vcur : own.y;
                 if (retest) { // LZ4_putPosition(ip - 2) in front of the re-test
                     const uint32_t v2 = have_v ? v2cur : (own.x >> 16) | (own.y << 16);
-                    tab[hash13(v2)] = (uint16_t)(ip - 2);
+                    tab_put(hash13(v2), ip - 2);
                 }
                 const uint32_t h = hash13(v);
-                match = tab[h];
-                tab[h] = (uint16_t)ip;
+                match = tab_get(h);
+                tab_put(h, ip);
                 uint32_t cat;
                 if (match >= 4) { cd = ld16g(g + match - 4); cat = cd.y; }
                 else cat = __builtin_amdgcn_alignbyte(first_hi, first_lo, match);
@@ -1607,6 +1626,7 @@ namespace {
 struct Workspace {
     uint32_t *p = nullptr; size_t cap = 0;
     uint16_t *lane_tabs = nullptr; size_t lane_cap = 0; // tables of the lane-per-block parser: 16 KiB per lane
+    hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; // the lane parser's stream beside the caller's
     std::mutex launch;
 };
 std::mutex ws_lock;
@@ -1641,6 +1661,7 @@ void lz4_release_workspaces()
     for (auto &kv : ws_map) {
         if (kv.second.p) (void)hipFree(kv.second.p);
         if (kv.second.lane_tabs) (void)hipFree(kv.second.lane_tabs);
+        if (kv.second.side) { (void)hipStreamDestroy(kv.second.side); (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); }
     }
     ws_map.clear();
 }
@@ -1722,15 +1743,20 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const int headw = hw_env ? atoi(hw_env) : 16;
     if (use_fp) lds = kTabBytes + kFpBytes;
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
-    // Large batches of blocks that are read from global memory: the lane-per-block parser first.  It looks at the queue
-    // length on the device and leaves everything to the wavefront-per-block parser below kLaneMinBlocks queued blocks.
-    // CW_LZ4_LANES=0 switches it off, =N sets the threshold; CW_LANES_WPC = its wavefronts per CU (profiling knobs).
+    // Large batches: the lane-per-block parser.  Two regimes:
+    //  * blocks read from global memory (> 4 KiB), from kLaneMinBlocks queued blocks on: the lanes take the whole queue, the
+    //    wavefront-per-block parser only what they leave (running it beside the lanes gains nothing there: both end up waiting
+    //    for the same memory system -- 33.1 vs 34.2 GB/s);
+    //  * LDS-staged blocks (<= 4 KiB), from kLaneMinSmall blocks on: the lanes run BESIDE the LDS-resident parser on a second
+    //    stream, both pulling from the scan's queue -- one is bound by LDS capacity and its chain latency, the other by random
+    //    memory accesses, and the rates add (4 KiB text: 26.2 -> 40.1 GB/s).
+    // The kernel looks at the queue length on the device and leaves everything to the wavefront parser below the threshold.
+    // CW_LZ4_LANES=0 switches it off, =N sets the threshold (1: every queued block, in the tests); CW_LANES_WPC = its
+    // wavefronts per CU, CW_LANES_CONCURRENT=0|1 forces the regime, CW_LANES_RESERVE the blocks left to the wavefronts.
     static const char *lanes_env = getenv("CW_LZ4_LANES");
-    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : kLaneMinBlocks;
-    bool lanes_used = false;
-    static const char *small_env = getenv("CW_LANES_SMALL"); // experiment: lanes also for blocks the LDS-staged parser takes
-    const bool lanes_small = small_env && small_env[0] == '1' && n >= 64;
-    if ((!staged || lanes_small) && !use_fp && lane_min && nblocks >= lane_min && n >= kMFLimit + 1) {
+    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : kLaneMinBlocks);
+    bool lanes_used = false, lanes_beside = false;
+    if (!use_fp && lane_min && nblocks >= lane_min && n >= 64) {
         static const char *lw_env = getenv("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
         size_t lgrid = (nblocks + 63) / 64;
@@ -1742,8 +1768,29 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             if (e != hipSuccess) return e;
             wsp.lane_cap = lgrid * 64;
         }
-        hipLaunchKernelGGL(lz4_lanes_kernel, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
-                           wsp.lane_tabs, lane_min);
+        // CW_LANES_CONCURRENT=0: one after the other on the caller's stream (the lanes take the whole queue); default: side by side
+        static const char *cc_env = getenv("CW_LANES_CONCURRENT");
+        static const char *rs_env = getenv("CW_LANES_RESERVE");
+        lanes_beside = cc_env ? cc_env[0] != '0' : staged;
+        uint32_t reserve = 0, lmin = lane_min;
+        if (lanes_beside) {
+            if (!wsp.side) {
+                if ((e = hipStreamCreateWithFlags(&wsp.side, hipStreamNonBlocking)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&wsp.fork, hipEventDisableTiming)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&wsp.join, hipEventDisableTiming)) != hipSuccess) return e;
+            }
+            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 49152u : 24576u);
+            if (lane_min > 1 && lmin < reserve + reserve / 2) lmin = reserve + reserve / 2; // (CW_LZ4_LANES=1 in the tests: no reserve)
+            if (lane_min == 1) reserve = 0;
+            if ((e = hipEventRecord(wsp.fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(wsp.side, wsp.fork, 0)) != hipSuccess) return e;
+        }
+        if (n <= 4096)
+            hipLaunchKernelGGL(lz4_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, lanes_beside ? wsp.side : stream, src, n, src_stride, dst,
+                               dst_stride, sizes, queue, counters, wsp.lane_tabs, lmin, reserve);
+        else
+            hipLaunchKernelGGL(lz4_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, lanes_beside ? wsp.side : stream, src, n, src_stride, dst,
+                               dst_stride, sizes, queue, counters, wsp.lane_tabs, lmin, reserve);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         lanes_used = true;
     }
@@ -1774,9 +1821,13 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                                dst_stride, sizes, queue, counters, queue2, force_redo);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (lanes_used && lanes_beside) { // the redo pass and the caller's later work wait for the lanes too
+        if ((e = hipEventRecord(wsp.join, wsp.side)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, wsp.join, 0)) != hipSuccess) return e;
+    }
     {
         static thread_local char names[160];
-        snprintf(names, sizeof names, "%s + %s%s", scan_name, lanes_used ? "cw::lz4_lanes_kernel (large queues) / " : "",
+        snprintf(names, sizeof names, "%s + %s%s", scan_name, lanes_used ? (lanes_beside ? "cw::lz4_lanes_kernel beside " : "cw::lz4_lanes_kernel (large queues), then ") : "",
                  cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
                  : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");
         note_kernels(0, names);

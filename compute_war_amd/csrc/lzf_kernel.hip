@@ -45,6 +45,18 @@ constexpr uint32_t kMaxOff = 1u << 13, kMaxRef = (1u << 8) + (1u << 3), kMaxLit 
 constexpr uint32_t kInLdsMax = 16384; // blocks up to this size are staged in LDS next to the table
 constexpr uint32_t kRedo = 0xFFFFFFFFu; // sizes[] marker: exchange kernel -> write/read-back kernel
 
+// Small blocks, large batches: the lane-per-block parser runs BESIDE the link/chain rounds (second stream).  The rounds walk
+// the batch from block 0 upwards, the lanes pull blocks from the top downwards; ctr[1] = blocks the lanes have taken,
+// ctr[2] = blocks the rounds have claimed (raised by a round's first kernel before it touches a block).  A lane pulls only
+// while more than `reserve` (>= two rounds) unclaimed blocks are left, so a block it takes can never be inside a claimed
+// round, and a round's kernels skip the blocks of theirs that the lanes took -- whatever the interleaving, every block is
+// parsed by exactly one side.  share == nullptr: no lanes beside (the rounds take everything).
+struct LaneShare { uint32_t *ctr; size_t round_first, total; };
+__device__ __forceinline__ bool lanes_took(const LaneShare &sh, uint32_t taken, size_t blk)
+{
+    return sh.ctr && sh.round_first + blk >= sh.total - taken;
+}
+
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 __device__ __forceinline__ uint32_t lzf_slot(uint32_t b0, uint32_t b1, uint32_t b2)
 {
@@ -413,8 +425,14 @@ __device__ __forceinline__ uint32_t load3(const uint8_t *g, uint32_t n, uint32_t
 
 __global__ void __launch_bounds__(64)
 lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint16_t *__restrict__ links,
-                 uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo)
+                 uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo, LaneShare share)
 {
+    uint32_t taken = 0;
+    if (share.ctr) { // claim this round's blocks, then see what the lanes already hold
+        if (threadIdx.x == 0) atomicMax(&share.ctr[2], (uint32_t)(share.round_first + nblocks));
+        taken = __hip_atomic_load(&share.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (share.round_first >= share.total - taken) return; // the whole round is theirs
+    }
     // LDS: the 128 KiB table, then the block (coalesced copy; positions are then read as aligned dwords)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *stage = smem + kLzfTabBytes; // kChainMax + 48 bytes
@@ -439,6 +457,10 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     if (vec) CW_PREFETCH(blockIdx.x);
 
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        if (lanes_took(share, taken, blk)) { // not ours: keep the prefetch pipeline in step and move on
+            if (vec) CW_PREFETCH(blk + gridDim.x);
+            continue;
+        }
         const uint8_t *g = src + blk * src_stride;
         uint16_t *out = links + blk * (size_t)n2;
         __syncthreads();
@@ -524,8 +546,13 @@ template <bool BIG>
 __global__ void __launch_bounds__(64)
 lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst,
                  size_t dst_stride, uint32_t *__restrict__ sizes, uint16_t *__restrict__ links, uint32_t n2,
-                 uint32_t *__restrict__ counter)
+                 uint32_t *__restrict__ counter, LaneShare share)
 {
+    uint32_t taken = 0;
+    if (share.ctr) {
+        taken = __hip_atomic_load(&share.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (share.round_first >= share.total - taken) return;
+    }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *E = reinterpret_cast<uint16_t *>(smem);          // !BIG: link | kSkipFlag, n2 entries
     uint8_t *stage = smem + 2 * (size_t)n2;                     // !BIG: the block, + 16 bytes of slack
@@ -541,6 +568,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
         __syncthreads();
         const size_t blk = __builtin_amdgcn_readfirstlane(mailbox);
         if (blk >= nblocks) break;
+        if (lanes_took(share, taken, blk)) continue;                       // a lane parses (or parsed) it
         if (__builtin_amdgcn_readfirstlane(sizes[blk]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
@@ -730,6 +758,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 // flags, no lane-order assumption: the parse is the serial one.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kLzfLaneMinBlocks = 24576;
+constexpr uint32_t kLzfLaneMinSmall = 262144; // blocks <= 4 KiB: lanes beside the rounds from 256 Ki blocks on
 
 // 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
 __device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32_t n)
@@ -738,10 +767,23 @@ __device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32
     return lz::rd32(g, q) >> ((ip - q) * 8);
 }
 
+// TAGGED (blocks <= 4 KiB): a table entry is epoch:4 | position:12, an entry of another epoch reads as empty, and the 128 KiB
+// table is zeroed once per 15 blocks instead of per block -- a 4 KiB block is ~1,300 parse iterations, zeroing its table 8,192
+// store iterations that the whole wavefront sits through whenever one of its lanes takes a new block.
+template <bool TAGGED>
 __global__ void __launch_bounds__(64)
 lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst, size_t dst_stride,
-                 uint32_t *__restrict__ sizes, uint16_t *__restrict__ tables, uint32_t *__restrict__ counter)
+                 uint32_t *__restrict__ sizes, uint16_t *__restrict__ tables, uint32_t *__restrict__ counter, uint32_t reserve)
 {
+    uint32_t epoch = 15; // TAGGED: forces a clean table before the first block
+    auto tab_get = [&](uint16_t *t, uint32_t slot) -> uint32_t {
+        const uint32_t e = t[slot];
+        return TAGGED ? ((e >> 12) == epoch ? e & 0xFFFu : 0u) : e;
+    };
+    auto tab_put = [&](uint16_t *t, uint32_t slot, uint32_t pos) { t[slot] = (uint16_t)(TAGGED ? (epoch << 12) | pos : pos); };
+    // reserve == 0: the lanes take every block, pulled upwards from counter[0].  reserve > 0: beside the link/chain rounds --
+    // blocks are pulled from the top downwards (counter[1]) while more than `reserve` unclaimed blocks are left (counter[2],
+    // see LaneShare)
     uint16_t *tab = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLzfSlots;
     const uint32_t cap = n - 1; // out_len of the reference's call (n >= 16 here)
     enum : uint32_t { NEXT = 0, STEP = 1, TAIL = 2, EXIT = 3 };
@@ -753,14 +795,27 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
     while (__ballot(state != EXIT)) {
         if (state == NEXT) {
-            blk = atomicAdd(counter, 1u);
+            if (reserve) {
+                const uint32_t taken = __hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t claimed = __hip_atomic_load(&counter[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk = nblocks; // = nothing
+                if ((size_t)taken + claimed + reserve < nblocks) {
+                    const uint32_t k = atomicAdd(&counter[1], 1u);
+                    if (k < nblocks) blk = nblocks - 1 - k; // pulled means parsed: the rounds skip everything >= nblocks - taken
+                }
+            } else {
+                blk = atomicAdd(counter, 1u);
+            }
             if (blk >= nblocks) {
                 state = EXIT;
             } else {
                 g = src + blk * src_stride;
                 out = dst + blk * dst_stride;
-                uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-                for (uint32_t i = 0; i < kLzfTabBytes / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                if (!TAGGED || ++epoch == 16) {
+                    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+                    for (uint32_t i = 0; i < kLzfTabBytes / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                    epoch = 1;
+                }
                 ip = 0; op = 1; lit = 0; fail = false; // op = 1: the first literal run's control byte is reserved
                 v = lzf_rd(g, 0, n);
                 state = STEP;
@@ -771,8 +826,8 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             // v = the 4 bytes at ip (requested an iteration ago)
             const uint32_t b0 = v & 0xFFu, b1 = (v >> 8) & 0xFFu, b2 = (v >> 16) & 0xFFu;
             const uint32_t slot = lzf_slot(b0, b1, b2);
-            const uint32_t ref = tab[slot];
-            tab[slot] = (uint16_t)ip;
+            const uint32_t ref = tab_get(tab, slot);
+            tab_put(tab, slot, ip);
             bool is_match = false;
             if (ref > 0 && ip - ref - 1 < kMaxOff) is_match = ((lz::rd32(g, ref) ^ v) & 0xFFFFFFu) == 0; // ref + 4 <= ip + 3 <= n
             if (is_match) {
@@ -820,8 +875,8 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                         state = TAIL;
                     } else { // VERY_FAST: only the last two positions of the match are inserted
                         const uint32_t w = lz::rd32(g, ip - 2); // bytes ip-2 .. ip+1
-                        tab[lzf_slot(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu)] = (uint16_t)(ip - 2);
-                        tab[lzf_slot((w >> 8) & 0xFFu, (w >> 16) & 0xFFu, w >> 24)] = (uint16_t)(ip - 1);
+                        tab_put(tab, lzf_slot(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu), ip - 2);
+                        tab_put(tab, lzf_slot((w >> 8) & 0xFFu, (w >> 16) & 0xFFu, w >> 24), ip - 1);
                         v = lzf_rd(g, ip, n);
                     }
                 }
@@ -863,6 +918,7 @@ namespace {
 struct LinkSpace {
     uint16_t *p = nullptr; size_t cap = 0; uint32_t *counter = nullptr;
     uint16_t *lane_tabs = nullptr; size_t lane_cap = 0; // tables of the lane-per-block parser: 128 KiB per lane
+    hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; // the lane parser's stream beside the rounds
 };
 struct LinkEntry { LinkSpace s; std::mutex launch; };
 std::mutex link_lock;
@@ -876,6 +932,7 @@ void lzf_release_workspaces()
         if (kv.second.s.p) (void)hipFree(kv.second.s.p);
         if (kv.second.s.counter) (void)hipFree(kv.second.s.counter);
         if (kv.second.s.lane_tabs) (void)hipFree(kv.second.s.lane_tabs);
+        if (kv.second.s.side) { (void)hipStreamDestroy(kv.second.s.side); (void)hipEventDestroy(kv.second.s.fork); (void)hipEventDestroy(kv.second.s.join); }
     }
     link_map.clear();
 }
@@ -913,7 +970,9 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const bool big = n > (lds_max < kChainMax ? lds_max : kChainMax);
         const uint32_t n2 = (n + 63u) & ~63u;
         const size_t ws_bytes = big ? (size_t)1 << 30 : (size_t)256 << 20; // links per round
-        const size_t chunk_max = ws_bytes / (2 * (size_t)n2);
+        static const char *round_env = getenv("CW_LZF_ROUND"); // test knob: blocks per round (many rounds on small data)
+        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : ws_bytes / (2 * (size_t)n2);
+        const size_t chunk_max = chunk_cap < ws_bytes / (2 * (size_t)n2) ? chunk_cap : ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
         LinkSpace ls;
         LinkEntry *entry;
@@ -922,12 +981,18 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             entry = &link_map[ws_key(stream)];
         }
         std::lock_guard<std::mutex> sequence(entry->launch); // the link array and the counter are shared by the launches below
-        // large batches of large blocks: the lane-per-block parser (CW_LZF_LANES=0 off, =N threshold; CW_LANES_WPC wavefronts per CU)
+        // Large batches: the lane-per-block parser (CW_LZF_LANES=0 off, =N threshold, 1 = every block, in the tests; CW_LANES_WPC
+        // wavefronts per CU).  Blocks > 4 KiB from kLzfLaneMinBlocks on: the lanes take the whole batch.  Blocks that fit the
+        // LDS-resident chain parser, from kLzfLaneMinSmall on: the lanes run BESIDE the link/chain rounds on a second stream,
+        // pulling from the top of the batch while the rounds climb from the bottom (LaneShare) -- one side is bound by LDS
+        // capacity and chain latency, the other by random memory accesses.
         static const char *lanes_env = getenv("CW_LZF_LANES");
-        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : kLzfLaneMinBlocks;
-        static const char *small_env = getenv("CW_LANES_SMALL"); // experiment: lanes also for blocks that fit the LDS scheme
-        const bool lanes_small = small_env && small_env[0] == '1';
-        if ((big || lanes_small) && lane_min && nblocks >= lane_min) {
+        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? kLzfLaneMinBlocks : kLzfLaneMinSmall);
+        static const char *cc_env = getenv("CW_LANES_CONCURRENT");
+        const bool use_lanes = lane_min && nblocks >= lane_min;
+        const bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
+        uint32_t lane_reserve = 0;
+        if (use_lanes) {
             static const char *lw_env = getenv("CW_LANES_WPC");
             const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 4;
             size_t lgrid = (nblocks + 63) / 64;
@@ -942,11 +1007,34 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 w.lane_cap = lgrid * 64;
             }
             if (!w.counter && (e = hipMalloc(reinterpret_cast<void **>(&w.counter), 64)) != hipSuccess) return e;
-            if ((e = hipMemsetAsync(w.counter, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(lzf_lanes_kernel, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride, sizes,
-                               w.lane_tabs, w.counter);
-            note_kernels(0, "cw::lzf_lanes_kernel");
-            return hipGetLastError();
+            if ((e = hipMemsetAsync(w.counter, 0, 16, stream)) != hipSuccess) return e;
+            if (!beside) {
+                if (n <= 4096)
+                    hipLaunchKernelGGL(lzf_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride,
+                                       sizes, w.lane_tabs, w.counter, 0u);
+                else
+                    hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride,
+                                       sizes, w.lane_tabs, w.counter, 0u);
+                note_kernels(0, "cw::lzf_lanes_kernel");
+                return hipGetLastError();
+            }
+            if (!w.side) {
+                if ((e = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&w.fork, hipEventDisableTiming)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
+            }
+            static const char *rs_env = getenv("CW_LANES_RESERVE");
+            lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (uint32_t)(2 * chunk + (round_env ? 0 : 16384));
+            if (lane_reserve < 2 * chunk) lane_reserve = (uint32_t)(2 * chunk); // never inside a claimed round (LaneShare)
+            if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;
+            if (n <= 4096)
+                hipLaunchKernelGGL(lzf_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, w.side, src, n, src_stride, nblocks, dst, dst_stride,
+                                   sizes, w.lane_tabs, w.counter, lane_reserve);
+            else
+                hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, w.side, src, n, src_stride, nblocks, dst, dst_stride,
+                                   sizes, w.lane_tabs, w.counter, lane_reserve);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         {
             LinkSpace &w = entry->s;
@@ -981,20 +1069,28 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             const uint8_t *s0 = src + first * src_stride;
             hipError_t e = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
             if (e != hipSuccess) return e;
+            const LaneShare share = {beside ? ls.counter : nullptr, first, nblocks};
             hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, s0, n, src_stride,
-                               nb, ls.p, n2, sizes + first, force_redo);
+                               nb, ls.p, n2, sizes + first, force_redo, share);
             const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
             if (big)
                 hipLaunchKernelGGL(lzf_chain_kernel<true>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
-                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter);
+                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter, share);
             else
                 hipLaunchKernelGGL(lzf_chain_kernel<false>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
-                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter);
+                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter, share);
             if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (beside) { // the redo pass and the caller's later work wait for the lanes too
+            hipError_t e = hipEventRecord(ls.join, ls.side);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ls.join, 0);
+            if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, in_lds, 1u);
-        note_kernels(0, big ? "cw::lzf_links_kernel + cw::lzf_chain_kernel<true>" : "cw::lzf_links_kernel + cw::lzf_chain_kernel<false>");
+        note_kernels(0, beside ? (big ? "cw::lzf_lanes_kernel beside cw::lzf_links_kernel + cw::lzf_chain_kernel<true>"
+                                      : "cw::lzf_lanes_kernel beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>")
+                               : big ? "cw::lzf_links_kernel + cw::lzf_chain_kernel<true>" : "cw::lzf_links_kernel + cw::lzf_chain_kernel<false>");
         return hipGetLastError();
     }
     if (!cut_only) {

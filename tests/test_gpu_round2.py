@@ -247,7 +247,7 @@ def test_lane_per_block_lz4_parser_is_exact():
         "rng = np.random.default_rng(5)\n"
         "sparse = rng.integers(0, 256, 3 * 65536, dtype=np.uint8); sparse[1000:1016] = sparse[200:216]; sparse[70000:70300] = 7\n"
         "data = corpus_file('lcet10.txt')[:6*65536] + bytes(65536) + corpus_file('kennedy.xls')[:5*65536] + corpus_file('ptt5')[:3*65536] + corpus_file('sum')[:32768] * 2 + sparse.tobytes()\n"
-        "for bs in (8192, 16384, 65536):\n"
+        "for bs in (8192, 16384, 65536, 4096, 1000):\n"
         "    sizes, payload = cw.compress_blocks('lz4', data, bs)\n"
         "    h = hashlib.sha256(sizes.tobytes())\n"
         "    for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
@@ -257,7 +257,7 @@ def test_lane_per_block_lz4_parser_is_exact():
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
-    assert len(outs[0]) == 3
+    assert len(outs[0]) == 5   # the last two sizes: LDS-staged blocks, the lanes run BESIDE the LDS-resident parser
     for a, b, c in zip(*outs):
         assert a[:3] == b[:3] == c[:3]
         assert "lz4_lanes_kernel" not in " ".join(a) and "lz4_lanes_kernel" in " ".join(b)
@@ -288,6 +288,19 @@ def test_lane_per_block_lzf_parser_is_exact():
     for a, b, c in zip(*outs):
         assert a[:4] == b[:4] == c[:4] and int(a[2]) > 0
         assert "lzf_lanes_kernel" not in " ".join(a) and "lzf_lanes_kernel" in " ".join(b)
+    # small blocks: the lanes run BESIDE the link/chain rounds (from the top of the batch downwards).  Rounds of 16 blocks
+    # (CW_LZF_ROUND, test knob) make a 2.6 MiB batch many rounds, so both sides and their meeting point are exercised.
+    prog2 = prog.replace("for bs in (8192, 16384, 65536):", "for bs in (4096, 1000, 2048):")
+    outs = []
+    for env in ({"CW_LZF_LANES": "0"}, {"CW_LZF_LANES": "1", "CW_LZF_ROUND": "16"}, {"CW_LZF_LANES": "1", "CW_LZF_ROUND": "16", "CW_LANES_WPC": "1"},
+                {"CW_LZF_LANES": "1", "CW_LZF_ROUND": "5", "CW_LANES_RESERVE": "10"}):
+        r = subprocess.run([sys.executable, "-c", prog2], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
+    assert len(outs[0]) == 3
+    for rows in zip(*outs):
+        assert all(r[:4] == rows[0][:4] for r in rows), rows
+        assert "lanes" not in " ".join(rows[0]) and "lzf_lanes_kernel beside" in " ".join(rows[1])
 
 
 def test_lane_parsers_odd_sizes_strides_and_alignment(oracle):
