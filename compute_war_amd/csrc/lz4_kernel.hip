@@ -36,6 +36,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 #include "cw_device.h"
@@ -1411,9 +1412,18 @@ __device__ __forceinline__ uint32_t win_at(const uint4 &q, uint32_t s)
     return s < 8 ? __builtin_amdgcn_alignbyte(q.z, q.y, s & 3u) : s < 12 ? __builtin_amdgcn_alignbyte(q.w, q.z, s & 3u) : q.w;
 }
 
-// TAGGED (blocks <= 4 KiB): a table entry is epoch:4 | position:12; an entry of another epoch reads as empty (= position 0,
-// as in the parser's zeroed table) and the table is zeroed once per 15 blocks instead of per block.
-template <bool TAGGED>
+// Table entries:
+//   kLaneTagged (blocks <= 4 KiB)  u16 epoch:4 | position:12; an entry of another epoch reads as empty (= position 0, as in the
+//                                  parser's zeroed table) and the table is zeroed once per 15 blocks instead of per block
+//   kLaneFp (blocks > 4 KiB)       u32 fingerprint:16 | position:16, the fingerprint being 16 further bits of the hash product of
+//                                  the 4 bytes the position was entered for: a candidate whose fingerprint differs holds other
+//                                  bytes and is not fetched (on text two candidates of three are such: the kernel is bound by
+//                                  the random 64-byte lines it draws from memory, and those are a third of them)
+//   kLanePlain                     u16 position (profiling: CW_LZ4_LANES_FP=0)
+enum : int { kLanePlain = 0, kLaneTagged = 1, kLaneFp = 2 };
+__device__ __forceinline__ uint32_t fp16(uint32_t v) { return ((v * 2654435761u) >> 3) & 0xFFFFu; }
+
+template <int MODE>
 __global__ void __launch_bounds__(64)
 lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                  uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
@@ -1421,18 +1431,28 @@ lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 {
     const uint32_t qcount = counters[1];
     if (qcount < min_blocks) return; // too few chains to fill the chip: the wavefront-per-block parser takes them all
+    // fewer queued blocks than lanes: the first qcount / 64 workgroups take them with every lane busy (all of the grid starting
+    // at once leaves each wavefront a random half of its lanes: mixed data, 64 Ki queued blocks on 128 Ki lanes, 79 vs 99 GB/s)
+    if ((size_t)blockIdx.x * 64 >= qcount) return;
     // reserve > 0: the wavefront-per-block parser runs BESIDE this kernel on another stream, pulling from the same queue (it
     // is bound by LDS capacity and its own latency, this kernel by random memory accesses: the rates add).  A block takes a lane
     // ~100 ms and a wavefront ~10 ms, so the lanes stop pulling while `reserve` blocks are left: the wavefronts finish those in
     // about the time the lanes need for the blocks they hold.
-    uint16_t *tab = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * (1u << 13);
+    constexpr bool TAGGED = MODE == kLaneTagged, FP = MODE == kLaneFp;
+    using Entry = typename std::conditional<FP, uint32_t, uint16_t>::type;
+    Entry *tab = reinterpret_cast<Entry *>(tables) + ((size_t)blockIdx.x * 64 + threadIdx.x) * (1u << 13);
     const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals; // n >= 13: a queued block had a match
     uint32_t epoch = 15; // TAGGED: forces a clean table before the first block
-    auto tab_get = [&](uint32_t h) -> uint32_t {
+    // the slot's position, and whether the bytes there can be the 4 bytes v at all
+    auto tab_get = [&](uint32_t h, uint32_t v, bool &maybe) -> uint32_t {
         const uint32_t e = tab[h];
+        maybe = true;
+        if (FP) { maybe = (e >> 16) == fp16(v); return e & 0xFFFFu; }
         return TAGGED ? ((e >> 12) == epoch ? e & 0xFFFu : 0u) : e;
     };
-    auto tab_put = [&](uint32_t h, uint32_t pos) { tab[h] = (uint16_t)(TAGGED ? (epoch << 12) | pos : pos); };
+    auto tab_put = [&](uint32_t h, uint32_t v, uint32_t pos) {
+        tab[h] = (Entry)(FP ? (fp16(v) << 16) | pos : TAGGED ? (epoch << 12) | pos : pos);
+    };
 
     uint32_t state = LS_NEXT;
     const uint8_t *g = src;
@@ -1475,11 +1495,12 @@ lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 out = dst + (size_t)blk * dst_stride;
                 if (!TAGGED || ++epoch == 16) {
                     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-                    for (uint32_t i = 0; i < (1u << 13) * 2 / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                    for (uint32_t i = 0; i < (1u << 13) * sizeof(Entry) / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
                     epoch = 1;
                 }
                 first_lo = rd32(g, 0); first_hi = rd32(g, 4);
-                // tab[hash(first 4 bytes)] = 0 is what an empty table already says
+                // tab[hash(first 4 bytes)] = 0 is what an empty table already says; with fingerprints the entry says whose 0 it is
+                if (FP) tab_put(hash13(first_lo), first_lo, 0);
                 ip = 1; anchor = 0; op = 0; step = 1; nb = 64; retest = false;
                 own.x = 0; own.y = rd32(g, 1); own.z = rd32(g, 5); own.w = rd32(g, 9); // no "before" at the block's start
                 have_v = false;
@@ -1495,14 +1516,17 @@ lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 const uint32_t v = have_v ? vcur : own.y;
                 if (retest) { // LZ4_putPosition(ip - 2) in front of the re-test
                     const uint32_t v2 = have_v ? v2cur : (own.x >> 16) | (own.y << 16);
-                    tab_put(hash13(v2), ip - 2);
+                    tab_put(hash13(v2), v2, ip - 2);
                 }
                 const uint32_t h = hash13(v);
-                match = tab_get(h);
-                tab_put(h, ip);
-                uint32_t cat;
-                if (match >= 4) { cd = ld16g(g + match - 4); cat = cd.y; }
-                else cat = __builtin_amdgcn_alignbyte(first_hi, first_lo, match);
+                bool maybe;
+                match = tab_get(h, v, maybe);
+                tab_put(h, v, ip);
+                uint32_t cat = ~v;
+                if (maybe) {
+                    if (match >= 4) { cd = ld16g(g + match - 4); cat = cd.y; }
+                    else cat = __builtin_amdgcn_alignbyte(first_hi, first_lo, match);
+                }
                 if (cat == v) {
                     state = LS_EMIT; // (own was requested for this ip an iteration ago: it is here by now)
                 } else {
@@ -1756,6 +1780,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     static const char *lanes_env = getenv("CW_LZ4_LANES");
     const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : kLaneMinBlocks);
     bool lanes_used = false, lanes_beside = false;
+    static const char *lf_env = getenv("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
+    const bool lanes_fp = !(lf_env && lf_env[0] == '0');
     if (!use_fp && lane_min && nblocks >= lane_min && n >= 64) {
         static const char *lw_env = getenv("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
@@ -1764,7 +1790,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if (wsp.lane_cap < lgrid * 64) {
             if (wsp.lane_tabs) { e = hipFree(wsp.lane_tabs); if (e != hipSuccess) return e; }
             wsp.lane_tabs = nullptr; wsp.lane_cap = 0;
-            e = hipMalloc(reinterpret_cast<void **>(&wsp.lane_tabs), lgrid * 64 * (size_t)kTabBytes);
+            e = hipMalloc(reinterpret_cast<void **>(&wsp.lane_tabs), lgrid * 64 * (size_t)kTabBytes * 2); // (entries of 4 bytes for blocks > 4 KiB)
             if (e != hipSuccess) return e;
             wsp.lane_cap = lgrid * 64;
         }
@@ -1779,18 +1805,22 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 if ((e = hipEventCreateWithFlags(&wsp.fork, hipEventDisableTiming)) != hipSuccess) return e;
                 if ((e = hipEventCreateWithFlags(&wsp.join, hipEventDisableTiming)) != hipSuccess) return e;
             }
-            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 49152u : 24576u);
-            if (lane_min > 1 && lmin < reserve + reserve / 2) lmin = reserve + reserve / 2; // (CW_LZ4_LANES=1 in the tests: no reserve)
+            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 8192u : 24576u); // measured 4 KiB text, 1 Mi blocks: 8 Ki..32 Ki 42.8 GB/s, 48 Ki 39.8
+            if (lane_min > 1 && lmin < 3 * reserve) lmin = 3 * reserve; // (CW_LZ4_LANES=1 in the tests: no reserve)
             if (lane_min == 1) reserve = 0;
             if ((e = hipEventRecord(wsp.fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(wsp.side, wsp.fork, 0)) != hipSuccess) return e;
         }
+        hipStream_t ls = lanes_beside ? wsp.side : stream;
         if (n <= 4096)
-            hipLaunchKernelGGL(lz4_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, lanes_beside ? wsp.side : stream, src, n, src_stride, dst,
-                               dst_stride, sizes, queue, counters, wsp.lane_tabs, lmin, reserve);
+            hipLaunchKernelGGL(lz4_lanes_kernel<kLaneTagged>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
+                               counters, wsp.lane_tabs, lmin, reserve);
+        else if (lanes_fp)
+            hipLaunchKernelGGL(lz4_lanes_kernel<kLaneFp>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
+                               counters, wsp.lane_tabs, lmin, reserve);
         else
-            hipLaunchKernelGGL(lz4_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, lanes_beside ? wsp.side : stream, src, n, src_stride, dst,
-                               dst_stride, sizes, queue, counters, wsp.lane_tabs, lmin, reserve);
+            hipLaunchKernelGGL(lz4_lanes_kernel<kLanePlain>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
+                               counters, wsp.lane_tabs, lmin, reserve);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         lanes_used = true;
     }
@@ -1826,7 +1856,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if ((e = hipStreamWaitEvent(stream, wsp.join, 0)) != hipSuccess) return e;
     }
     {
-        static thread_local char names[160];
+        static thread_local char names[192];
         snprintf(names, sizeof names, "%s + %s%s", scan_name, lanes_used ? (lanes_beside ? "cw::lz4_lanes_kernel beside " : "cw::lz4_lanes_kernel (large queues), then ") : "",
                  cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
                  : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");

@@ -758,7 +758,9 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 // flags, no lane-order assumption: the parse is the serial one.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kLzfLaneMinBlocks = 24576;
-constexpr uint32_t kLzfLaneMinSmall = 262144; // blocks <= 4 KiB: lanes beside the rounds from 256 Ki blocks on
+constexpr uint32_t kLzfLaneMinSmall = 49152;  // blocks <= 4 KiB: lanes beside the rounds from 48 Ki blocks on (64 Ki: 19.1 vs 13.8 GB/s)
+constexpr size_t kLzfBesideRound = 8192;      // ... in rounds of 8 Ki blocks, the last two rounds' worth left to the rounds (LaneShare):
+                                              // 4 KiB text, 1 Mi blocks: 32.2 GB/s; rounds of 32 Ki blocks (reserve 80 Ki) 28.4; of 4 Ki 29.9
 
 // 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
 __device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32_t n)
@@ -971,7 +973,12 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const uint32_t n2 = (n + 63u) & ~63u;
         const size_t ws_bytes = big ? (size_t)1 << 30 : (size_t)256 << 20; // links per round
         static const char *round_env = getenv("CW_LZF_ROUND"); // test knob: blocks per round (many rounds on small data)
-        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : ws_bytes / (2 * (size_t)n2);
+        static const char *lanes_env = getenv("CW_LZF_LANES");
+        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? kLzfLaneMinBlocks : kLzfLaneMinSmall);
+        static const char *cc_env = getenv("CW_LANES_CONCURRENT");
+        const bool use_lanes = lane_min && nblocks >= lane_min;
+        const bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
+        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? kLzfBesideRound : ws_bytes / (2 * (size_t)n2);
         const size_t chunk_max = chunk_cap < ws_bytes / (2 * (size_t)n2) ? chunk_cap : ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
         LinkSpace ls;
@@ -986,11 +993,6 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         // LDS-resident chain parser, from kLzfLaneMinSmall on: the lanes run BESIDE the link/chain rounds on a second stream,
         // pulling from the top of the batch while the rounds climb from the bottom (LaneShare) -- one side is bound by LDS
         // capacity and chain latency, the other by random memory accesses.
-        static const char *lanes_env = getenv("CW_LZF_LANES");
-        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? kLzfLaneMinBlocks : kLzfLaneMinSmall);
-        static const char *cc_env = getenv("CW_LANES_CONCURRENT");
-        const bool use_lanes = lane_min && nblocks >= lane_min;
-        const bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
         uint32_t lane_reserve = 0;
         if (use_lanes) {
             static const char *lw_env = getenv("CW_LANES_WPC");
@@ -1024,7 +1026,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
             }
             static const char *rs_env = getenv("CW_LANES_RESERVE");
-            lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (uint32_t)(2 * chunk + (round_env ? 0 : 16384));
+            lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (uint32_t)(2 * chunk);
             if (lane_reserve < 2 * chunk) lane_reserve = (uint32_t)(2 * chunk); // never inside a claimed round (LaneShare)
             if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;

@@ -253,14 +253,15 @@ def test_lane_per_block_lz4_parser_is_exact():
         "    for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
         "    print(bs, int(sizes.sum()), h.hexdigest(), cw.profile_kernels()['codec'])\n" % (ROOT, ROOT))
     outs = []
-    for env in ({}, {"CW_LZ4_LANES": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}):
+    # blocks > 4 KiB: table entries carry a fingerprint of the 4 bytes (CW_LZ4_LANES_FP=0: plain 16-bit entries)
+    for env in ({}, {"CW_LZ4_LANES": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_FP": "0"}):
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
     assert len(outs[0]) == 5   # the last two sizes: LDS-staged blocks, the lanes run BESIDE the LDS-resident parser
-    for a, b, c in zip(*outs):
-        assert a[:3] == b[:3] == c[:3]
-        assert "lz4_lanes_kernel" not in " ".join(a) and "lz4_lanes_kernel" in " ".join(b)
+    for rows in zip(*outs):
+        assert all(r[:3] == rows[0][:3] for r in rows), rows
+        assert "lanes" not in " ".join(rows[0]) and "lz4_lanes_kernel" in " ".join(rows[1])
 
 
 def test_lane_per_block_lzf_parser_is_exact():
@@ -337,7 +338,7 @@ def test_lane_parsers_odd_sizes_strides_and_alignment(oracle):
     assert len(outs[0]) == 8
     for a, b in zip(*outs):
         assert a[:4] == b[:4], (a, b)
-        assert "lanes_kernel" not in " ".join(a) and "lanes_kernel" in " ".join(b)
+        assert "lanes" not in " ".join(a) and "lanes" in " ".join(b)
     # and the reference run itself against the oracle, for one of the shapes
     text = corpus_file("fields.c") + corpus_file("cp.html") + corpus_file("sum") + corpus_file("ptt5")[:90000]
     bs, nb, sstride, shift = 5001, 40, 5001, 3
