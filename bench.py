@@ -19,6 +19,7 @@ and, at N = 1, further timed legs under "legs" -- outside `value`, each with its
 cpu_baseline -- that time what uniform noise cannot: the codecs' match/emit path:
   mixed                 Skein-512 + LZ4, 64 KiB, SURVEY 8(d)'s compressible synthetic mix (cw_dev_gen_mixed)
   corpus_skein512_lz4   BASELINE configs[2]: the in-tree corpora (canterbury + canterbury-large) tiled in HBM, 64 KiB
+  corpus_skein256_lz4_4k  the reference's own default pair and block size (hc_sklz4: Skein-256-128 + LZ4 at 4 KiB, run_tests:19)
   corpus_sha256_lzf_4k / _64k   BASELINE configs[3], the reference's hc_shlzf pair (run_tests:20), 4 KiB and 64 KiB
 plus "host_path": the drop-in host-buffer entry point (PCIe-inclusive, never `value`).
 """
@@ -502,6 +503,7 @@ def main():
         bsec = 0.0 if args.no_cpu_baseline else 4.0
         for name, h, c, b, kind in (("mixed", "skein512", "lz4", 65536, "mixed"),
                                     ("corpus_skein512_lz4", "skein512", "lz4", 65536, "corpus"),
+                                    ("corpus_skein256_lz4_4k", "skein", "lz4", 4096, "corpus"),
                                     ("corpus_sha256_lzf_4k", "sha256mb", "lzf", 4096, "corpus"),
                                     ("corpus_sha256_lzf_64k", "sha256mb", "lzf", 65536, "corpus")):
             leg, _ = run_leg(cw, torch, args, name, h, c, b, lb // b, kind, 3, 1, 1, 0, local_rank, 0, bsec)

@@ -19,11 +19,15 @@
 //                first hit => the block index is queued.  lz4_scan_span_kernel (power-of-two sizes 4..64 KiB, 64 KiB
 //                spans, straight-line memory operations), lz4_scan_stream_kernel (other aligned sizes and span
 //                tails), lz4_scan_kernel (unaligned: gathers).
-//   2. parse  -- lz4_lanes_kernel (large blocks, >= 24 Ki of them queued): one block per LANE, the serial parser as it
-//                stands, tables in global memory -- tens of thousands of chains instead of the 2,560 that LDS admits;
-//                lz4_parse_kernel (everything else): full parse of the queued blocks, one block per wavefront; the table
-//                operation of a batch of items is one ds_mskor_rtn_b32 exchange whose lanes the LDS applies in ascending
-//                order (verified per batch).  lz4_parse_fp_kernel: a diagnostic variant (CW_LZ4_PARSE=fp).
+//   2. parse  -- lz4_lanes_kernel: one block per LANE, the serial parser as it stands, tables in global memory -- tens of
+//                thousands of chains instead of the 2,560 that LDS admits.  Blocks > 4 KiB, from 24 Ki queued blocks on: it
+//                takes the whole queue.  Blocks <= 4 KiB, from 96 Ki blocks on: it runs BESIDE lz4_parse_kernel on a second
+//                stream, both pulling from the scan's queue (one is bound by LDS capacity and chain latency, the other by
+//                random memory lines: the rates add).
+//                lz4_parse_kernel (everything else, and what the lanes leave): full parse of the queued blocks, one block per
+//                wavefront; the table operation of a batch of items is one ds_mskor_rtn_b32 exchange whose lanes the LDS
+//                applies in ascending order (verified per batch).  lz4_parse_fp_kernel: a diagnostic variant
+//                (CW_LZ4_PARSE=fp).
 //   3. redo   -- lz4_blocks_kernel: the first-generation parser (write/read-back collision detection, batch cut,
 //                rollback), run on the blocks the parse kernel hands back when its lane-order check fails (never
 //                observed; forced in the tests).

@@ -15,13 +15,16 @@
 // is exact too.
 //
 // Kernels (DESIGN.md 4.4 has the measurements):
-//   > 4 KiB, >= 24 Ki blocks:  lzf_lanes_kernel (one block per LANE, liblzf's loop as it stands, 128 KiB table per lane in
-//                      global memory);
-//   blocks <= 16 KiB:  lzf_links_kernel (per-position "previous position with my slot", 128 KiB table, throughput
-//                      bound) + lzf_chain_kernel (parse on link chains + skip flags: 12.3 KiB of LDS per 4 KiB block,
-//                      13 blocks per CU, no table writes);
-//   larger blocks:     lzf_parse_kernel (128 KiB table in LDS, one block per CU; table operation of a batch = one
-//                      ds_mskor_rtn_b32 exchange, lanes in ascending order, verified per batch);
+//   lzf_lanes_kernel   one block per LANE, liblzf's loop as it stands, 128 KiB table per lane in global memory.  Blocks
+//                      > 4 KiB, from 24 Ki blocks on: the whole batch.  Blocks <= 4 KiB, from 48 Ki blocks on: BESIDE the
+//                      link/chain rounds on a second stream, the lanes pulling from the top of the batch while the rounds
+//                      climb from the bottom (LaneShare);
+//   lzf_links_kernel + lzf_chain_kernel   (everything else from 16 bytes on) per-position "previous position with my slot"
+//                      (128 KiB table, throughput bound), then the parse on link chains + skip flags with no table: blocks
+//                      <= 4 KiB with links and block in LDS (12.3 KiB, 13 blocks per CU), larger ones with only the skip
+//                      bits in LDS;
+//   lzf_parse_kernel   (blocks < 16 bytes; CW_LZF_MODE=table) 128 KiB table in LDS, one block per CU; table operation of a
+//                      batch = one ds_mskor_rtn_b32 exchange, lanes in ascending order, verified per batch;
 //   redo:              lzf_blocks_kernel, the first-generation parser (write/read-back collision detection, batch
 //                      cut, rollback) for blocks whose lane-order check failed (never observed; forced in the tests).
 

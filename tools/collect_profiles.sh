@@ -6,16 +6,18 @@
 set -e
 TAG=${1:-r02}
 O=gpurun_out/$TAG; mkdir -p $O
+LEGS=("mixed skein512 lz4 65536 mixed" "corpus_skein512_lz4 skein512 lz4 65536 corpus" "corpus_skein256_lz4_4k skein lz4 4096 corpus"
+      "corpus_sha256_lzf_4k sha256mb lzf 4096 corpus" "corpus_sha256_lzf_64k sha256mb lzf 65536 corpus")
 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -20 $O/bench_default.err; exit 1; }
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats -d $O/prof_headline -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline > $O/prof_headline.json 2> $O/prof_headline.err
-for leg in "mixed skein512 lz4 65536 mixed" "corpus_skein512_lz4 skein512 lz4 65536 corpus" "corpus_sha256_lzf_4k sha256mb lzf 4096 corpus" "corpus_sha256_lzf_64k sha256mb lzf 65536 corpus"; do
+for leg in "${LEGS[@]}"; do
   set -- $leg
   rocprofv3 --kernel-trace --stats -d $O/prof_$1 -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --hash $2 --comp $3 --block-bytes $4 --data $5 --blocks-per-gpu $(( (4<<30) / $4 )) --steps 3 --warmup 1 > $O/prof_$1.json 2> $O/prof_$1.err
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $O/pmc_headline_$c -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_headline_$c.log 2>&1
-  for leg in "mixed skein512 lz4 65536 mixed" "corpus_skein512_lz4 skein512 lz4 65536 corpus" "corpus_sha256_lzf_4k sha256mb lzf 4096 corpus" "corpus_sha256_lzf_64k sha256mb lzf 65536 corpus"; do
+  for leg in "${LEGS[@]}"; do
     set -- $leg
     rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$1_$c -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --hash $2 --comp $3 --block-bytes $4 --data $5 --blocks-per-gpu $(( (4<<30) / $4 )) --steps 1 --warmup 0 > $O/pmc_$1_$c.log 2>&1
   done

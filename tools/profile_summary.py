@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEGS = {"headline": ("skein512", "lz4", 65536, 1 << 20, "random"),
         "mixed": ("skein512", "lz4", 65536, 65536, "mixed"),
         "corpus_skein512_lz4": ("skein512", "lz4", 65536, 65536, "corpus"),
+        "corpus_skein256_lz4_4k": ("skein", "lz4", 4096, 1 << 20, "corpus"),
         "corpus_sha256_lzf_4k": ("sha256mb", "lzf", 4096, 1 << 20, "corpus"),
         "corpus_sha256_lzf_64k": ("sha256mb", "lzf", 65536, 65536, "corpus")}
 
