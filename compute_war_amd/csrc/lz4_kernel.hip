@@ -1649,6 +1649,321 @@ lz4_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Lane-per-block parser with the lane's input in an LDS ring (blocks > 4 KiB).
+//
+// tools/random_line.hip: the chip retires about 17.5 G "probes" per second of the lanes' pattern (a table entry loaded and
+// stored at a random slot of a private table, a candidate's 16 bytes for every third), whatever the occupancy and whether or
+// not the addresses depend on loaded data -- the lane parsers are bound by lines, not by latency.  lz4_lanes_kernel spends
+// lines on more than probes: the 16 bytes around every position and the literals of every sequence are global loads of their
+// own.  Here the block's bytes reach the lane once, in 64-byte pieces requested an iteration and more ahead of their use and
+// kept in a 256-byte ring per lane in LDS (16 KiB per wavefront); positions, windows and literals are read from the ring, and
+// memory sees the table entry, the candidates the fingerprint lets through, and the output.
+//
+// An iteration of the wavefront's loop:
+//   A  every searching lane hashes its next K positions (the parser's own sequence of steps; a re-test after a match is the
+//      batch's first entry) out of the ring and requests the K table entries; lanes extending a long match request the
+//      next 32 bytes of both sides
+//   B  the piece requested an iteration ago goes into the ring; entries arrive; a position whose slot an earlier position of
+//      the batch (or the re-test's ip-2) also hashes to takes that position instead, as it would have read it; the candidates
+//      whose fingerprint fits are requested
+//   C  the first position whose candidate matches wins, the table takes the positions up to it (the parser never looked at
+//      the rest), the sequence is emitted from the ring and the candidate's window; without a winner the search goes on
+//      behind the batch.
+// K = 1 ships: more positions per iteration cut the round trips per sequence, but the entries and candidates behind the
+// winner are extra lines (K = 4: 26 GB/s against 36 GB/s without the fingerprints).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kRingBytes = 256, kRingPiece = 64;
+enum : uint32_t { LB_NEXT = 0, LB_PROBE = 1, LB_EXTEND = 2, LB_TAIL = 3, LB_EXIT = 4 };
+
+// stores exactly cnt (1..16) bytes of (a, b)
+__device__ __forceinline__ void lane_store_upto16(uint8_t *p, uint64_t a, uint64_t b, uint32_t cnt)
+{
+    if (cnt & 16) { __builtin_memcpy(p, &a, 8); __builtin_memcpy(p + 8, &b, 8); return; }
+    if (cnt & 8) { __builtin_memcpy(p, &a, 8); a = b; p += 8; }
+    if (cnt & 4) { const uint32_t t = (uint32_t)a; __builtin_memcpy(p, &t, 4); a >>= 32; p += 4; }
+    if (cnt & 2) { const uint16_t t = (uint16_t)a; __builtin_memcpy(p, &t, 2); a >>= 16; p += 2; }
+    if (cnt & 1) *p = (uint8_t)a;
+}
+
+template <int K>
+__global__ void __launch_bounds__(64)
+lz4_lanes_ring_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                      uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
+                      uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve)
+{
+    __shared__ uint32_t ring[(kRingBytes / 4) * 64]; // dword d of lane l's ring at [d * 64 + l]: a lane only touches its column
+    const uint32_t qcount = counters[1];
+    if (qcount < min_blocks) return;
+    if ((size_t)blockIdx.x * 64 >= qcount) return; // (as in lz4_lanes_kernel)
+    const uint32_t lane = threadIdx.x;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(tables) + ((size_t)blockIdx.x * 64 + lane) * (1u << 13); // fingerprint:16 | position:16
+    const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals; // n >= 64
+
+    // bytes [x, x+4) / [x, x+16) of the block out of the ring (the caller knows they are there)
+    auto ring_dw = [&](uint32_t x) -> uint32_t { return ring[((x >> 2) & (kRingBytes / 4 - 1)) * 64 + lane]; };
+    auto ring32 = [&](uint32_t x) -> uint32_t { return __builtin_amdgcn_alignbyte(ring_dw(x + 4), ring_dw(x), x & 3u); };
+    auto ring16 = [&](uint32_t x) -> uint4 {
+        const uint32_t d0 = ring_dw(x), d1 = ring_dw(x + 4), d2 = ring_dw(x + 8), d3 = ring_dw(x + 12), d4 = ring_dw(x + 16), r = x & 3u;
+        return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, r), __builtin_amdgcn_alignbyte(d2, d1, r), __builtin_amdgcn_alignbyte(d3, d2, r),
+                          __builtin_amdgcn_alignbyte(d4, d3, r));
+    };
+
+    uint32_t state = LB_NEXT;
+    const uint8_t *g = src;
+    uint8_t *out = dst;
+    uint32_t blk = 0, ip = 0, anchor = 0, op = 0, step = 1, nb = 64, match = 0, first_lo = 0, first_hi = 0;
+    bool retest = false;
+    uint32_t rb = 0, re = 0;            // the ring holds the block's bytes [rb, re)
+    uint4 fl0, fl1, fl2, fl3;           // the piece [re, re + 64) on its way
+    fl0 = fl1 = fl2 = fl3 = make_uint4(0, 0, 0, 0);
+    bool inflight = false;
+    uint32_t mc = 0, tok = 0, token = 0; // a sequence whose match is still being extended
+
+    while (__ballot(state != LB_EXIT)) {
+        if (state == LB_NEXT) {
+            uint32_t qi = qcount;
+            if (!reserve || __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + reserve < qcount)
+                qi = atomicAdd(&counters[0], 1u);
+            if (qi >= qcount) {
+                state = LB_EXIT;
+            } else {
+                blk = queue[qi];
+                g = src + (size_t)blk * src_stride;
+                out = dst + (size_t)blk * dst_stride;
+                uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+                for (uint32_t i = 0; i < (1u << 13) * 4 / 16; i++) t4[i] = make_uint4(0, 0, 0, 0);
+                first_lo = rd32(g, 0); first_hi = rd32(g, 4);
+                tab[hash13(first_lo)] = fp16(first_lo) << 16; // position 0, by name (an empty entry has fingerprint 0)
+                ip = 1; anchor = 0; op = 0; step = 1; nb = 64; retest = false;
+                rb = 0; re = 0; inflight = false;
+                state = LB_PROBE;
+            }
+        }
+        // a lane that searches needs a piece on its way whenever its ring ends less than 104 bytes ahead (the most a batch
+        // advances is 16 + 12, the piece requested now is usable two iterations on); a match that jumped over the ring's end
+        // restarts the ring at the new position
+        if (state == LB_PROBE && !inflight) {
+            if (ip >= 4 + kRingPiece && ip - 4 - kRingPiece >= re) rb = re = (ip - 4) & ~(kRingPiece - 1);
+            if (re < n && re < ip + 104) {
+                const uint8_t *q = g + re;
+                if (re + kRingPiece <= n) {
+                    fl0 = ld16g(q); fl1 = ld16g(q + 16); fl2 = ld16g(q + 32); fl3 = ld16g(q + 48);
+                } else { // the block's last piece: byte by byte, zeros behind the block
+                    uint32_t w[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t x = re + 4 * i + b;
+                            if (x < n) v |= (uint32_t)g[x] << (8 * b);
+                        }
+                        w[i] = v;
+                    }
+                    fl0 = make_uint4(w[0], w[1], w[2], w[3]); fl1 = make_uint4(w[4], w[5], w[6], w[7]);
+                    fl2 = make_uint4(w[8], w[9], w[10], w[11]); fl3 = make_uint4(w[12], w[13], w[14], w[15]);
+                }
+                inflight = true;
+            }
+        }
+
+        // ---------------- A: positions, hashes, table requests ----------------
+        uint32_t pos[K], hsh[K], val[K], raw[K];
+        uint32_t cnt = 0, h2 = 0xFFFFFFFFu, v2 = 0, after_ip = 0, after_step = 0, after_nb = 0;
+        bool tail_after = false;
+        const bool searching = state == LB_PROBE && re >= (ip + 24 < n ? ip + 24 : n); // (rb <= ip - 4 by construction)
+        if (searching) {
+            uint32_t p = ip, st = step, c = nb;
+            if (retest) { // LZ4_putPosition(ip - 2) in front of the re-test
+                v2 = ring32(ip - 2);
+                h2 = hash13(v2);
+                tab[h2] = fp16(v2) << 16 | (ip - 2);
+            }
+            bool building = true;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                pos[j] = hsh[j] = val[j] = raw[j] = 0;
+                if (building) {
+                    const bool is_rt = retest && j == 0;
+                    if (!is_rt && p + st > mflimit + 1) { tail_after = true; building = false; }
+                    else if (p - ip > 12) building = false;
+                    else {
+                        pos[j] = p; val[j] = ring32(p); hsh[j] = hash13(val[j]); cnt = j + 1;
+                        raw[j] = tab[hsh[j]];
+                        if (is_rt) { p = p + 1; st = 1; c = 64; }
+                        else { p = p + st; st = c >> 6; c++; }
+                    }
+                }
+            }
+            after_ip = p; after_step = st; after_nb = c;
+        }
+        uint4 xa0, xb0, xa1, xb1;
+        xa0 = xb0 = xa1 = xb1 = make_uint4(0, 0, 0, 0);
+        uint32_t ext_vec = 0;
+        if (state == LB_EXTEND) {
+            const uint32_t a = ip + kMinMatch + mc, b = match + kMinMatch + mc;
+            if (a + 32 <= matchlimit) { xa0 = ld16g(g + a); xb0 = ld16g(g + b); xa1 = ld16g(g + a + 16); xb1 = ld16g(g + b + 16); ext_vec = 2; }
+            else if (a + 16 <= matchlimit) { xa0 = ld16g(g + a); xb0 = ld16g(g + b); ext_vec = 1; }
+        }
+
+        // ---------------- B: the piece requested an iteration ago goes into the ring; candidates ----------------
+        if (inflight) {
+            const uint32_t d = (re >> 2) & (kRingBytes / 4 - 1);
+            uint32_t *r = ring + d * 64 + lane;
+            r[0 * 64] = fl0.x; r[1 * 64] = fl0.y; r[2 * 64] = fl0.z; r[3 * 64] = fl0.w;
+            r[4 * 64] = fl1.x; r[5 * 64] = fl1.y; r[6 * 64] = fl1.z; r[7 * 64] = fl1.w;
+            r[8 * 64] = fl2.x; r[9 * 64] = fl2.y; r[10 * 64] = fl2.z; r[11 * 64] = fl2.w;
+            r[12 * 64] = fl3.x; r[13 * 64] = fl3.y; r[14 * 64] = fl3.z; r[15 * 64] = fl3.w;
+            re += kRingPiece;
+            if (re > rb + kRingBytes) rb = re - kRingBytes;
+            inflight = false;
+        }
+        uint32_t mt[K];
+        bool maybe[K];
+        uint4 cdw[K];
+        if (searching) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                uint32_t m = raw[j] & 0xFFFFu;
+                bool may = (raw[j] >> 16) == fp16(val[j]);
+                if (hsh[j] == h2) { m = ip - 2; may = v2 == val[j]; }
+#pragma unroll
+                for (int i = 0; i < j; i++)
+                    if ((uint32_t)i < cnt && hsh[i] == hsh[j]) { m = pos[i]; may = val[i] == val[j]; }
+                mt[j] = m;
+                maybe[j] = may && (uint32_t)j < cnt;
+                cdw[j] = make_uint4(0, 0, 0, 0);
+                if (maybe[j] && m >= 4) cdw[j] = ld16g(g + m - 4);
+            }
+        }
+
+        // ---------------- C: winner, table, sequence ----------------
+        bool emit = false;
+        uint4 cd = make_uint4(0, 0, 0, 0);
+        if (searching) {
+            uint32_t win = K;
+#pragma unroll
+            for (int j = K - 1; j >= 0; j--) {
+                const uint32_t cat = mt[j] >= 4 ? cdw[j].y : __builtin_amdgcn_alignbyte(first_hi, first_lo, mt[j]);
+                if (maybe[j] && cat == val[j]) win = (uint32_t)j;
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++)
+                if ((uint32_t)j < cnt && (uint32_t)j <= win) tab[hsh[j]] = fp16(val[j]) << 16 | pos[j];
+            if (win < K) {
+#pragma unroll
+                for (int j = 0; j < K; j++)
+                    if (win == (uint32_t)j) { ip = pos[j]; match = mt[j]; cd = cdw[j]; }
+                emit = true;
+            } else if (tail_after) {
+                state = LB_TAIL;
+            } else {
+                ip = after_ip; step = after_step; nb = after_nb; retest = false;
+            }
+        }
+        bool finish = false; // the sequence's match length is known: token, length bytes, advance
+        if (emit) {
+            const uint32_t ip0 = ip;
+            const bool windows = ip >= 4 && match >= 4;
+            uint32_t nf = 0; // equal bytes behind the 4 that matched
+            bool nf_open = true;
+            if (windows) {
+                const uint4 own = ring16(ip - 4);
+                const uint64_t x = ((uint64_t)own.w << 32 | own.z) ^ ((uint64_t)cd.w << 32 | cd.z);
+                nf = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                nf_open = nf == 8;
+                const uint32_t lim = matchlimit - (ip0 + kMinMatch);
+                if (nf >= lim) { nf = lim; nf_open = false; }
+                // catch-up over the pending literals (none right after a match: anchor == ip)
+                const uint32_t room = ip - anchor < match ? ip - anchor : match;
+                const uint32_t y = own.x ^ cd.x;
+                uint32_t back = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+                if (back > room) back = room;
+                ip -= back; match -= back;
+                if (back == 4) while (ip > anchor && match > 0 && g[ip - 1] == g[match - 1]) { ip--; match--; }
+            } else {
+                while (ip > anchor && match > 0 && g[ip - 1] == g[match - 1]) { ip--; match--; }
+            }
+            const uint32_t lit = ip - anchor;
+            tok = op++;
+            if (lit >= 15) { token = 15u << 4; lane_put_len(out, op, lit - 15); }
+            else token = lit << 4;
+            if (lit) {
+                if (anchor >= rb) { // out of the ring (ip <= re: the run's bytes are all there)
+                    for (uint32_t k = 0; k < lit; k += 16) {
+                        const uint4 q = ring16(anchor + k);
+                        lane_store_upto16(out + op + k, (uint64_t)q.y << 32 | q.x, (uint64_t)q.w << 32 | q.z, lit - k < 16 ? lit - k : 16);
+                    }
+                } else { // a run longer than the ring remembers
+                    uint32_t k = 0;
+                    for (; k + 8 <= lit; k += 8) {
+                        uint64_t q;
+                        __builtin_memcpy(&q, g + anchor + k, 8);
+                        __builtin_memcpy(out + op + k, &q, 8);
+                    }
+                    for (; k < lit; k++) out[op + k] = g[anchor + k];
+                }
+            }
+            op += lit;
+            const uint32_t off = ip - match;
+            out[op] = (uint8_t)off; out[op + 1] = (uint8_t)(off >> 8);
+            op += 2;
+            mc = ip0 - ip + nf; // the bytes taken back, the 4 that matched and the nf behind them are one run
+            if (nf_open) state = LB_EXTEND;
+            else finish = true;
+        } else if (state == LB_EXTEND) {
+            const uint32_t a = ip + kMinMatch, b = match + kMinMatch;
+            bool open = true;
+            if (ext_vec) {
+                const uint64_t d0 = ((uint64_t)xa0.y << 32 | xa0.x) ^ ((uint64_t)xb0.y << 32 | xb0.x);
+                const uint64_t d1 = ((uint64_t)xa0.w << 32 | xa0.z) ^ ((uint64_t)xb0.w << 32 | xb0.z);
+                if (d0) { mc += (uint32_t)__builtin_ctzll(d0) >> 3; open = false; }
+                else if (d1) { mc += 8 + ((uint32_t)__builtin_ctzll(d1) >> 3); open = false; }
+                else {
+                    mc += 16;
+                    if (ext_vec == 2) {
+                        const uint64_t d2 = ((uint64_t)xa1.y << 32 | xa1.x) ^ ((uint64_t)xb1.y << 32 | xb1.x);
+                        const uint64_t d3 = ((uint64_t)xa1.w << 32 | xa1.z) ^ ((uint64_t)xb1.w << 32 | xb1.z);
+                        if (d2) { mc += (uint32_t)__builtin_ctzll(d2) >> 3; open = false; }
+                        else if (d3) { mc += 8 + ((uint32_t)__builtin_ctzll(d3) >> 3); open = false; }
+                        else mc += 16;
+                    }
+                }
+            } else { // fewer than 16 bytes to the match limit
+                while (a + mc < matchlimit && g[a + mc] == g[b + mc]) mc++;
+                open = false;
+            }
+            if (!open) finish = true;
+        }
+        if (finish) {
+            if (mc >= 15) { token += 15; lane_put_len(out, op, mc - 15); }
+            else token += mc;
+            out[tok] = (uint8_t)token;
+            ip += kMinMatch + mc;
+            anchor = ip;
+            if (ip > mflimit) state = LB_TAIL;
+            else { retest = true; state = LB_PROBE; }
+        }
+
+        if (state == LB_TAIL) {
+            const uint32_t run = n - anchor;
+            if (run >= 15) { out[op++] = 15u << 4; lane_put_len(out, op, run - 15); }
+            else out[op++] = (uint8_t)(run << 4);
+            uint32_t k = 0;
+            for (; k + 16 <= run; k += 16) {
+                uint4 q;
+                __builtin_memcpy(&q, g + anchor + k, 16);
+                __builtin_memcpy(out + op + k, &q, 16);
+            }
+            for (; k < run; k++) out[op + k] = g[anchor + k];
+            op += run;
+            sizes[blk] = op;
+            state = LB_NEXT;
+        }
+    }
+}
+
 // per-stream workspace: counters[8] (parse queue head, tail; scan feed; -; second queue head, tail) + two queues
 namespace {
 struct Workspace {
@@ -1786,6 +2101,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     bool lanes_used = false, lanes_beside = false;
     static const char *lf_env = getenv("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
     const bool lanes_fp = !(lf_env && lf_env[0] == '0');
+    static const char *lr_env = getenv("CW_LZ4_LANES_RING"); // 0 = input from global memory (lz4_lanes_kernel); 1, 2 = positions per iteration
+    const int lanes_ring = lr_env ? atoi(lr_env) : 1;
     if (!use_fp && lane_min && nblocks >= lane_min && n >= 64) {
         static const char *lw_env = getenv("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
@@ -1818,6 +2135,12 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         hipStream_t ls = lanes_beside ? wsp.side : stream;
         if (n <= 4096)
             hipLaunchKernelGGL(lz4_lanes_kernel<kLaneTagged>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
+                               counters, wsp.lane_tabs, lmin, reserve);
+        else if (lanes_ring == 1)
+            hipLaunchKernelGGL(lz4_lanes_ring_kernel<1>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
+                               counters, wsp.lane_tabs, lmin, reserve);
+        else if (lanes_ring == 2)
+            hipLaunchKernelGGL(lz4_lanes_ring_kernel<2>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
                                counters, wsp.lane_tabs, lmin, reserve);
         else if (lanes_fp)
             hipLaunchKernelGGL(lz4_lanes_kernel<kLaneFp>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
@@ -1861,7 +2184,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     {
         static thread_local char names[192];
-        snprintf(names, sizeof names, "%s + %s%s", scan_name, lanes_used ? (lanes_beside ? "cw::lz4_lanes_kernel beside " : "cw::lz4_lanes_kernel (large queues), then ") : "",
+        const bool ringk = n > 4096 && (lanes_ring == 1 || lanes_ring == 2);
+        snprintf(names, sizeof names, "%s + %s%s%s", scan_name, lanes_used ? (ringk ? "cw::lz4_lanes_ring_kernel" : "cw::lz4_lanes_kernel") : "",
+                 lanes_used ? (lanes_beside ? " beside " : " (large queues), then ") : "",
                  cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
                  : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");
         note_kernels(0, names);

@@ -253,15 +253,18 @@ def test_lane_per_block_lz4_parser_is_exact():
         "    for i in range(len(sizes)): h.update(payload[i, :sizes[i]].tobytes())\n"
         "    print(bs, int(sizes.sum()), h.hexdigest(), cw.profile_kernels()['codec'])\n" % (ROOT, ROOT))
     outs = []
-    # blocks > 4 KiB: table entries carry a fingerprint of the 4 bytes (CW_LZ4_LANES_FP=0: plain 16-bit entries)
-    for env in ({}, {"CW_LZ4_LANES": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_FP": "0"}):
+    # blocks > 4 KiB: the ring form (input in an LDS ring, fingerprints in the table; CW_LZ4_LANES_RING=2: two positions per
+    # iteration, =0: lz4_lanes_kernel with / without fingerprints, which blocks <= 4 KiB always use in its tagged form)
+    for env in ({}, {"CW_LZ4_LANES": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "2"},
+                {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "0"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "0", "CW_LZ4_LANES_FP": "0"}):
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln.split() for ln in r.stdout.strip().splitlines()])
     assert len(outs[0]) == 5   # the last two sizes: LDS-staged blocks, the lanes run BESIDE the LDS-resident parser
     for rows in zip(*outs):
         assert all(r[:3] == rows[0][:3] for r in rows), rows
-        assert "lanes" not in " ".join(rows[0]) and "lz4_lanes_kernel" in " ".join(rows[1])
+        assert "lanes" not in " ".join(rows[0]) and "lz4_lanes" in " ".join(rows[1])
+    assert "lz4_lanes_ring_kernel" in " ".join(outs[1][0]) and "lz4_lanes_kernel" in " ".join(outs[4][0])
 
 
 def test_lane_per_block_lzf_parser_is_exact():

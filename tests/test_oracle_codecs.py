@@ -148,3 +148,20 @@ def test_cpu_hashandcompress_worker_loop(oracle):
         assert dig[i].tobytes() == hashlib.sha256(b).digest()
         c = oracle.lzf_compress(b)
         assert sizes[i] == len(c) and payload[i, :len(c)].tobytes() == c
+
+
+def test_probe_count_tool_emulates_the_parser(oracle):
+    """tools/lz_probe_count.py (work counts quoted in DESIGN.md 4.3) is a pure-Python walk of the LZ4 parser: its output sizes
+    must be the oracle's."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lz_probe_count", os.path.join(root, "tools", "lz_probe_count.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    data = corpus_file("lcet10.txt")[:3 * 65536] + corpus_file("kennedy.xls")[:65536]
+    for bs in (65536, 4096):
+        for i in range(0, len(data), bs * 5):
+            blk = data[i:i + bs]
+            probes, seqs, out = mod.lz4_counts(blk)
+            assert out == len(oracle.lz4_compress(blk)) and probes >= seqs > 0
