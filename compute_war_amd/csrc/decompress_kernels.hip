@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cw_device.h"
 
@@ -124,11 +125,178 @@ decompress_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const ui
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Lane-per-block decoders for large batches of large blocks.  A 64 KiB block fills the LDS budget of the wavefront decoder
+// with its output alone (two blocks per CU) and its token chain is serial: 7.7 / 6.0 GB/s.  Here a LANE decodes a block
+// straight from its slot into its place in dst -- the decoder's loop as it stands, 64 per wavefront, bound like the
+// lane-per-block parsers by the lines the memory system retires: per sequence one 16-byte window of the compressed stream
+// (token, short literal run and offset in one load when they fit), the literals' store, the match's load(s) from the lane's
+// own earlier output and its store(s).  A match closer than 16 bytes is copied at a multiple of its offset (the output is
+// periodic there), doubling until 16-byte pieces go through.  Same checks as above: nothing is read outside [0, n) of the
+// slot or written outside the block.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void store_upto16(uint8_t *p, uint64_t a, uint64_t b, uint32_t cnt)
+{
+    if (cnt & 16) { __builtin_memcpy(p, &a, 8); __builtin_memcpy(p + 8, &b, 8); return; }
+    if (cnt & 8) { __builtin_memcpy(p, &a, 8); a = b; p += 8; }
+    if (cnt & 4) { const uint32_t t = (uint32_t)a; __builtin_memcpy(p, &t, 4); a >>= 32; p += 4; }
+    if (cnt & 2) { const uint16_t t = (uint16_t)a; __builtin_memcpy(p, &t, 2); a >>= 16; p += 2; }
+    if (cnt & 1) *p = (uint8_t)a;
+}
+
+// d[op .. op+len) = d[op-off ..), the format's overlapping copy; off >= 1, op - off >= 0, op + len <= cap (checked by the caller)
+__device__ __forceinline__ void lane_copy_match(uint8_t *d, uint32_t op, uint32_t off, uint32_t len, uint32_t cap)
+{
+    const uint32_t base = op - off, end = op + len;
+    uint32_t dist = off;
+    while (op < end) {
+        while (dist < 16 && 2 * dist <= op - base) dist *= 2; // any multiple of off that is already written is a period
+        const uint32_t left = end - op, piece = left < 16 ? left : 16, cnt = piece < dist ? piece : dist;
+        const uint32_t s = op - dist;
+        if (s + 16 <= cap) {
+            uint64_t a, b;
+            __builtin_memcpy(&a, d + s, 8);
+            __builtin_memcpy(&b, d + s + 8, 8);
+            store_upto16(d + op, a, b, cnt);
+        } else {
+            for (uint32_t k = 0; k < cnt; k++) d[op + k] = d[s + k];
+        }
+        op += cnt;
+    }
+}
+
+// d[op .. op+len) = in[ip ..): literal bytes; ip + len <= n and op + len <= cap checked by the caller
+__device__ __forceinline__ void lane_copy_literals(uint8_t *d, uint32_t op, const uint8_t *in, uint32_t ip, uint32_t len, uint32_t n)
+{
+    uint32_t k = 0;
+    for (; k < len; k += 16) {
+        const uint32_t cnt = len - k < 16 ? len - k : 16;
+        if (ip + k + 16 <= n) {
+            uint64_t a, b;
+            __builtin_memcpy(&a, in + ip + k, 8);
+            __builtin_memcpy(&b, in + ip + k + 8, 8);
+            store_upto16(d + op + k, a, b, cnt);
+        } else {
+            for (uint32_t j = 0; j < cnt; j++) d[op + k + j] = in[ip + k + j];
+        }
+    }
+}
+} // namespace
+
+template <int ALG>
+__global__ void __launch_bounds__(64)
+decompress_lanes_kernel(const uint8_t *__restrict__ comp, size_t comp_stride, const uint32_t *__restrict__ sizes, size_t nblocks,
+                        uint8_t *__restrict__ dst, uint32_t block_bytes, uint32_t *__restrict__ status)
+{
+    const size_t lanes = (size_t)gridDim.x * 64;
+    for (size_t blk = (size_t)blockIdx.x * 64 + threadIdx.x; blk < nblocks; blk += lanes) {
+        const uint8_t *in = comp + blk * comp_stride;
+        uint8_t *d = dst + blk * (size_t)block_bytes;
+        const uint32_t n = sizes[blk];
+        uint32_t ip = 0, op = 0;
+        bool bad = n == 0 || n > comp_stride || n > (1u << 24);
+        if (ALG == 0) {
+            while (!bad) {
+                if (ip >= n) { bad = true; break; }
+                // token, a literal run of up to 13 bytes and the offset in one window when the slot has 16 bytes left
+                uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                const bool win = ip + 16 <= n;
+                if (win) { uint4 q; __builtin_memcpy(&q, in + ip, 16); w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w; }
+                const uint32_t tok = win ? w0 & 0xFFu : in[ip];
+                uint32_t lit = tok >> 4, ml = tok & 15;
+                uint32_t off;
+                if (win && lit <= 13) {
+                    if (lit > block_bytes - op) { bad = true; break; }
+                    // literals = window bytes [1, 1 + lit)
+                    const uint64_t lo = (uint64_t)w1 << 32 | w0, hi = (uint64_t)w3 << 32 | w2;
+                    const uint64_t a = lo >> 8 | hi << 56, b = hi >> 8;
+                    if (lit) store_upto16(d + op, a, b, lit);
+                    op += lit;
+                    ip += 1 + lit;
+                    if (ip == n) break; // (a window means 16 bytes were left: not the last sequence unless lit == 15.. never here)
+                    const uint32_t sh = (1 + lit) * 8; // offset = window bytes [1 + lit, 3 + lit)
+                    const uint64_t o = sh < 64 ? (lo >> sh | (sh ? hi << (64 - sh) : 0)) : hi >> (sh - 64);
+                    off = (uint32_t)o & 0xFFFFu;
+                    ip += 2;
+                } else {
+                    ip++;
+                    if (lit == 15) {
+                        uint32_t c;
+                        do { if (ip >= n) { bad = true; break; } c = in[ip]; ip++; lit += c; } while (c == 255);
+                        if (bad) break;
+                    }
+                    if (lit > n - ip || lit > block_bytes - op) { bad = true; break; }
+                    lane_copy_literals(d, op, in, ip, lit, n);
+                    ip += lit; op += lit;
+                    if (ip == n) break; // last sequence: literals only
+                    if (n - ip < 2) { bad = true; break; }
+                    off = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8);
+                    ip += 2;
+                }
+                if (off == 0 || off > op) { bad = true; break; }
+                if (ml == 15) {
+                    uint32_t c;
+                    do { if (ip >= n) { bad = true; break; } c = in[ip]; ip++; ml += c; } while (c == 255);
+                    if (bad) break;
+                }
+                if (ml > block_bytes || ml + 4 > block_bytes - op) { bad = true; break; }
+                ml += 4;
+                lane_copy_match(d, op, off, ml, block_bytes);
+                op += ml;
+            }
+        } else {
+            while (!bad && ip < n) {
+                const uint32_t ctrl = in[ip]; ip++;
+                if (ctrl < 32) {
+                    const uint32_t run = ctrl + 1;
+                    if (run > n - ip || run > block_bytes - op) { bad = true; break; }
+                    lane_copy_literals(d, op, in, ip, run, n);
+                    ip += run; op += run;
+                } else {
+                    uint32_t len = ctrl >> 5;
+                    if (ip >= n) { bad = true; break; }
+                    if (len == 7) { len += in[ip]; ip++; if (ip >= n) { bad = true; break; } }
+                    const uint32_t off = (((ctrl & 0x1f) << 8) | in[ip]) + 1; ip++;
+                    len += 2;
+                    if (off > op || len > block_bytes - op) { bad = true; break; }
+                    lane_copy_match(d, op, off, len, block_bytes);
+                    op += len;
+                }
+            }
+        }
+        if (op != block_bytes) bad = true;
+        status[blk] = bad ? 1u : 0u;
+    }
+}
+
 hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, uint8_t *dst,
                              size_t block_bytes, uint32_t *status, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536) return hipErrorInvalidValue;
+    // Large batches: one block per lane (CW_DECODE_LANES=0 off / =N threshold in blocks).  A lane needs ~0.37 (LZ4) / 0.57 (LZF) us
+    // per KiB of block whatever the batch, the wavefront decoders run at 75 / 44 / 22 / 8 GB/s for 4 / 8 / 16 / 64 KiB blocks of
+    // text: the lanes win from about 128 MiB of blocks on, and never below ~3,000 blocks (measured: 64 KiB x 2,048 6.1 vs 7.9 GB/s,
+    // x 4,096 11.1 vs 7.8, x 65,536 97.7 vs 7.9; 4 KiB x 512 Ki 109.6 vs 75.5).  Unlike the wavefront decoder, which assembles a
+    // block in LDS and only stores it when it decoded cleanly, a lane writes as it goes: the bytes of a block with status 1 are
+    // unspecified either way.
+    static const char *dl_env = getenv("CW_DECODE_LANES");
+    const size_t by_bytes = ((size_t)128 << 20) / block_bytes;
+    const size_t lane_min = dl_env ? (size_t)atoi(dl_env) : (by_bytes > 4096 ? by_bytes : 4096);
+    if (lane_min && nblocks >= lane_min) {
+        static const char *lw_env = getenv("CW_LANES_WPC");
+        const size_t wpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
+        size_t lgrid = (nblocks + 63) / 64;
+        if (lgrid > 256 * wpc) lgrid = 256 * wpc;
+        if (alg == 0)
+            hipLaunchKernelGGL(decompress_lanes_kernel<0>, dim3((unsigned)lgrid), dim3(64), 0, stream, comp, comp_stride, sizes, nblocks, dst,
+                               (uint32_t)block_bytes, status);
+        else
+            hipLaunchKernelGGL(decompress_lanes_kernel<1>, dim3((unsigned)lgrid), dim3(64), 0, stream, comp, comp_stride, sizes, nblocks, dst,
+                               (uint32_t)block_bytes, status);
+        return hipGetLastError();
+    }
     // LDS: the decoded block, and -- if at least four blocks per CU still fit (blocks up to ~16 KiB: 4 KiB text decodes
     // 2.2x faster, 64 KiB 1.6x slower with it) -- the compressed slot (at most the codec's bound)
     const uint32_t out_bytes = (uint32_t)((block_bytes + 15) & ~(size_t)15);

@@ -2184,8 +2184,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     {
         static thread_local char names[192];
-        const bool ringk = n > 4096 && (lanes_ring == 1 || lanes_ring == 2);
-        snprintf(names, sizeof names, "%s + %s%s%s", scan_name, lanes_used ? (ringk ? "cw::lz4_lanes_ring_kernel" : "cw::lz4_lanes_kernel") : "",
+        const char *lname = n <= 4096 ? "cw::lz4_lanes_kernel<1>" : lanes_ring == 1 ? "cw::lz4_lanes_ring_kernel<1>" : lanes_ring == 2 ? "cw::lz4_lanes_ring_kernel<2>"
+                            : lanes_fp ? "cw::lz4_lanes_kernel<2>" : "cw::lz4_lanes_kernel<0>"; // (as rocprofv3 prints the instantiations)
+        snprintf(names, sizeof names, "%s + %s%s%s", scan_name, lanes_used ? lname : "",
                  lanes_used ? (lanes_beside ? " beside " : " (large queues), then ") : "",
                  cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
                  : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");

@@ -1020,7 +1020,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 else
                     hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride,
                                        sizes, w.lane_tabs, w.counter, 0u);
-                note_kernels(0, "cw::lzf_lanes_kernel");
+                note_kernels(0, n <= 4096 ? "cw::lzf_lanes_kernel<true>" : "cw::lzf_lanes_kernel<false>");
                 return hipGetLastError();
             }
             if (!w.side) {
@@ -1093,8 +1093,9 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         }
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, in_lds, 1u);
-        note_kernels(0, beside ? (big ? "cw::lzf_lanes_kernel beside cw::lzf_links_kernel + cw::lzf_chain_kernel<true>"
-                                      : "cw::lzf_lanes_kernel beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>")
+        note_kernels(0, beside ? (big ? "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<true>"
+                                      : n <= 4096 ? "cw::lzf_lanes_kernel<true> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>"
+                                                  : "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>")
                                : big ? "cw::lzf_links_kernel + cw::lzf_chain_kernel<true>" : "cw::lzf_links_kernel + cw::lzf_chain_kernel<false>");
         return hipGetLastError();
     }

@@ -304,7 +304,7 @@ def test_lane_per_block_lzf_parser_is_exact():
     assert len(outs[0]) == 3
     for rows in zip(*outs):
         assert all(r[:4] == rows[0][:4] for r in rows), rows
-        assert "lanes" not in " ".join(rows[0]) and "lzf_lanes_kernel beside" in " ".join(rows[1])
+        assert "lanes" not in " ".join(rows[0]) and "lzf_lanes_kernel<true> beside" in " ".join(rows[1])
 
 
 def test_lane_parsers_odd_sizes_strides_and_alignment(oracle):
@@ -399,3 +399,60 @@ def test_driver_devices_flag_and_rccl_totals(oracle):
     assert f"devices=1 in={nblocks * bs} out={out} (ncclAllReduce over the per-device totals)" in lines
     r = subprocess.run([exe, "--devices", "9", paths[0]], capture_output=True, text=True)
     assert r.returncode == 2 and "out of range" in r.stderr
+
+
+def test_lane_per_block_decoders():
+    """CW_DECODE_LANES=1 sends every batch through the lane-per-block decoders (normally from about 128 MiB of blocks
+    on): round trips of the mixed corpus at 64 KiB and at an odd size, oracle-made streams with runs (offset 1 / 3 / 256 matches
+    of tens of kilobytes), and the malformed inputs of the wavefront decoders' tests -- truncated, an offset in front of the
+    block, sizes beyond the slot -- which must give status 1 and nothing else."""
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, torch, compute_war_amd as cw\n"
+        "from conftest import corpus_file, corpus_names\n"
+        "import oracle\n"
+        "cw.init(0)\n"
+        "s = torch.cuda.current_stream().cuda_stream\n"
+        "data = b''.join(corpus_file(n) for n in corpus_names())\n"
+        "rng = np.random.default_rng(3)\n"
+        "for bs in (65536, 20001, 4100):\n"
+        "    nb = 96\n"
+        "    a = np.frombuffer((data * 4)[:nb * bs], dtype=np.uint8).copy()\n"
+        "    a[5 * bs:6 * bs] = rng.integers(0, 256, bs, dtype=np.uint8); a[7 * bs:8 * bs] = 0; a[9 * bs:10 * bs] = np.tile(np.arange(3, dtype=np.uint8), bs)[:bs]\n"
+        "    src = torch.from_numpy(a).cuda()\n"
+        "    for comp in ('lz4', 'lzf'):\n"
+        "        stride = (cw.compress_bound(comp, bs) + 15) // 16 * 16\n"
+        "        dst = torch.zeros(nb * stride, dtype=torch.uint8, device='cuda'); sizes = torch.zeros(nb, dtype=torch.int32, device='cuda')\n"
+        "        back = torch.zeros(nb * bs, dtype=torch.uint8, device='cuda'); status = torch.full((nb,), 7, dtype=torch.int32, device='cuda')\n"
+        "        cw.dev_compress(comp, src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s)\n"
+        "        cw.dev_decompress(comp, dst.data_ptr(), stride, sizes.data_ptr(), nb, back.data_ptr(), bs, status.data_ptr(), s)\n"
+        "        torch.cuda.synchronize()\n"
+        "        fits = sizes != 0\n"
+        "        assert bool((status[fits] == 0).all()) and bool((status[~fits] == 1).all()), (comp, bs, status.cpu().tolist())\n"
+        "        ok = (back.view(nb, bs) == src.view(nb, bs)).all(dim=1)\n"
+        "        assert bool(ok[fits].all()), (comp, bs)\n"
+        "        print('roundtrip', comp, bs, int(fits.sum()))\n"
+        "bs = 32768\n"
+        "blocks = [corpus_file('alice29.txt')[:bs], bytes(bs), bytes(range(256)) * (bs // 256), (b'abc' * bs)[:bs], corpus_file('ptt5')[:bs]]\n"
+        "for comp, enc in (('lz4', oracle.lz4_compress), ('lzf', oracle.lzf_compress)):\n"
+        "    stride = (cw.compress_bound(comp, bs) + 15) // 16 * 16\n"
+        "    k = len(blocks)\n"
+        "    buf = np.zeros((k + 5, stride), dtype=np.uint8); sz = np.zeros(k + 5, dtype=np.uint32)\n"
+        "    for i, b in enumerate(blocks):\n"
+        "        c = enc(b); buf[i, :len(c)] = np.frombuffer(c, dtype=np.uint8); sz[i] = len(c)\n"
+        "    c = enc(blocks[0]); buf[k, :len(c) - 7] = np.frombuffer(c[:-7], dtype=np.uint8); sz[k] = len(c) - 7\n"
+        "    bad = (bytes([0x10, 65, 0xFF, 0x7F]) + bytes(20)) if comp == 'lz4' else bytes([0, 65, 0xFF, 0xFF, 0]) + bytes(20)\n"
+        "    buf[k + 1, :len(bad)] = np.frombuffer(bad, dtype=np.uint8); sz[k + 1] = len(bad)\n"
+        "    buf[k + 2:, :len(c)] = np.frombuffer(c, dtype=np.uint8); sz[k + 2:] = [stride + 1, 0xFFFFFFF0, 1 << 25]\n"
+        "    d_buf, d_sz = torch.from_numpy(buf).cuda(), torch.from_numpy(sz.view(np.int32)).cuda()\n"
+        "    back = torch.zeros((k + 5, bs), dtype=torch.uint8, device='cuda'); status = torch.full((k + 5,), 7, dtype=torch.int32, device='cuda')\n"
+        "    cw.dev_decompress(comp, d_buf.data_ptr(), stride, d_sz.data_ptr(), k + 5, back.data_ptr(), bs, status.data_ptr(), s)\n"
+        "    torch.cuda.synchronize()\n"
+        "    st, hb = status.cpu().tolist(), back.cpu().numpy()\n"
+        "    assert st == [0] * k + [1] * 5, (comp, st)\n"
+        "    for i, b in enumerate(blocks): assert hb[i].tobytes() == b, (comp, i)\n"
+        "    print('streams', comp, st)\n" % (ROOT, ROOT))
+    for env in ({"CW_DECODE_LANES": "1"}, {"CW_DECODE_LANES": "1", "CW_LANES_WPC": "1"}, {"CW_DECODE_LANES": "0"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        assert r.stdout.count("roundtrip") == 6 and r.stdout.count("streams") == 2

@@ -1,3 +1,5 @@
+"""Decoded bytes per second of cw_dev_decompress on lcet10-tiled text: `decode_probe.py [total MiB] [block sizes...]`
+(CW_DECODE_LANES=0 keeps the wavefront decoders for every batch)."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch, compute_war_amd as cw
@@ -5,8 +7,8 @@ cw.init(0)
 s = torch.cuda.current_stream().cuda_stream
 t = open("tests/golden/corpus/canterbury/lcet10.txt", "rb").read()
 for alg in ("lz4", "lzf"):
-    for bs in (4096, 65536):
-        nb = (256 << 20) // bs
+    for bs in ([int(x) for x in sys.argv[2:]] or [4096, 65536]):
+        nb = ((int(sys.argv[1]) if len(sys.argv) > 1 else 256) << 20) // bs
         data = (t * (nb * bs // len(t) + 1))[: nb * bs]
         src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
         stride = (cw.compress_bound(alg, bs) + 15) // 16 * 16

@@ -47,8 +47,11 @@ def main():
                         "tools/collect_profiles.sh: bench.py --no-legs --steps 1 --warmup 0 at the leg's own size), summed over the launches "
                         "of the step. FETCH_SIZE is doubled (gfx950 counts 128-B requests of 16 B/lane streaming loads as 64 B, "
                         "MI355X_MICROARCH.md); for scattered narrow loads (the parse kernels' candidates) that correction is an upper bound. "
-                        f"Raw per-kernel sums: profiles/{tag}_pmc_summary.txt"}
-    lines = []
+                        "Counter collection serialises kernels: in the legs whose parsers run side by side (4 KiB blocks) the lane kernel, "
+                        "which starts first, takes every block but its reserve, so those sums describe that division of work, not the "
+                        f"timed one. Raw per-kernel sums: profiles/{tag}_pmc_summary.txt"}
+    lines = ["(rocprofv3 --pmc serialises kernels: where a lane kernel runs BESIDE the LDS-resident parser -- the 4 KiB legs -- it starts",
+             " first and takes every block but its reserve; per-block figures divide by all blocks of the step)", ""]
     for leg, (h, c, bs, nb, kind) in LEGS.items():
         ks = os.path.join(src, f"prof_{leg}", "p_kernel_stats.csv")
         if os.path.exists(ks):
