@@ -21,7 +21,9 @@ cpu_baseline -- that time what uniform noise cannot: the codecs' match/emit path
   corpus_skein512_lz4   BASELINE configs[2]: the in-tree corpora (canterbury + canterbury-large) tiled in HBM, 64 KiB
   corpus_skein256_lz4_4k  the reference's own default pair and block size (hc_sklz4: Skein-256-128 + LZ4 at 4 KiB, run_tests:19)
   corpus_sha256_lzf_4k / _64k   BASELINE configs[3], the reference's hc_shlzf pair (run_tests:20), 4 KiB and 64 KiB
-plus "host_path": the drop-in host-buffer entry point (PCIe-inclusive, never `value`).
+plus "host_path": the drop-in host-buffer entry point (PCIe-inclusive, never `value`).  After its timed region every leg checks
+sampled blocks bit-exact against the oracle ("parity_spot_check") and decodes ALL of its slots on the device, comparing them with
+their input blocks ("roundtrip"); a mismatch aborts the run instead of printing a number.
 """
 from __future__ import annotations
 
@@ -55,6 +57,7 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline leg only")
+    ap.add_argument("--no-roundtrip", action="store_true", help="skip the full-size decode-and-compare after each leg")
     ap.add_argument("--leg-bytes", type=int, default=4 << 30, help="input bytes per extra leg")
     ap.add_argument("--standalone", action="store_true",
                     help="after the timed region also launch each kernel alone (3x) and report its own roofline; off by default so "
@@ -289,6 +292,30 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
             nsample = max(host_cpu_share(), min(nb, (256 << 20) // bs))
             sample = src[: nsample * bs].cpu().numpy()
 
+    # full-size round trip (outside the timed region): every block this rank compressed is decoded on the device and compared
+    # with its input -- a check that does not depend on the oracle and covers all of the leg's blocks, not a sample
+    roundtrip = None
+    if not args.no_roundtrip:
+        t_rt = time.perf_counter()
+        chunk = max(1, min(nb, (2 << 30) // bs))
+        back = torch.empty(chunk * bs, dtype=torch.uint8, device="cuda")
+        status = torch.empty(chunk, dtype=torch.int32, device="cuda")
+        wrong = raw = 0
+        for first in range(0, nb, chunk):
+            k = min(chunk, nb - first)
+            cw.dev_decompress(comp_name, dst.data_ptr() + first * stride, stride, sizes.data_ptr() + first * 4, k, back.data_ptr(), bs,
+                              status.data_ptr(), s)
+            fits = sizes[first:first + k] != 0          # LZF: 0 = did not fit l - 1, the caller keeps the block raw
+            same = (back[:k * bs].view(k, bs) == src[first * bs:(first + k) * bs].view(k, bs)).all(dim=1) & (status[:k] == 0)
+            wrong += int((fits & ~same).sum().item())
+            raw += int((~fits).sum().item())
+            del same
+        del back, status
+        if wrong:
+            raise SystemExit(f"ROUND-TRIP FAILURE in bench leg {name}: {wrong} of {nb} blocks do not decode to their input")
+        roundtrip = {"blocks_decoded_and_compared": nb - raw, "stored_raw": raw, "ok": True, "seconds": round(time.perf_counter() - t_rt, 2),
+                     "how": "cw_dev_decompress of every slot on the device, compared with the input block"}
+
     if rank != 0:
         return None, None
     csize = bytes_out / total_blocks
@@ -319,6 +346,8 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
         "kernels": dict(kernels, note="codec and hash run concurrently on two streams; durations overlap"),
         "parity_spot_check": spot,
     }
+    if roundtrip:
+        leg["roundtrip"] = roundtrip
     if per_corpus:
         leg["corpus_ratios"] = per_corpus
     if solo_ms:
@@ -484,6 +513,8 @@ def main():
         "kernels": head["kernels"],
         "parity_spot_check": head["parity_spot_check"],
     }
+    if "roundtrip" in head:
+        out["roundtrip"] = head["roundtrip"]
     if "standalone" in head:
         out["standalone"] = head["standalone"]
     # the binding roof of the Skein-512 kernel is integer VALU issue, not HBM; the peak is derived in a tracked
