@@ -456,3 +456,50 @@ def test_lane_per_block_decoders():
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert r.returncode == 0, (env, r.stderr[-2000:])
         assert r.stdout.count("roundtrip") == 6 and r.stdout.count("streams") == 2
+
+
+def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
+    """At the sizes where the launch policy itself switches the lane parsers on -- 256 Ki blocks of 4 KiB (lanes BESIDE the
+    LDS-resident parsers, real interleavings of the shared queue / the top-down and bottom-up claims) and 32 Ki blocks of 64 KiB
+    (lanes take the queue) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
+    (CW_LZ4_LANES=0 CW_LZF_LANES=0), which the parity tests pin to the oracle.  Compared through a Skein-512 digest per 64 KiB of
+    the packed stream, computed on the device."""
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, torch, compute_war_amd as cw\n"
+        "from conftest import corpus_file, corpus_names\n"
+        "cw.init(0)\n"
+        "s = torch.cuda.current_stream().cuda_stream\n"
+        "data = b''.join(corpus_file(n) for n in corpus_names())\n"
+        "rng = np.random.default_rng(11)\n"
+        "for bs, nb in ((4096, 262144), (65536, 32768)):\n"
+        "    a = np.frombuffer((data * (nb * bs // len(data) + 1))[:nb * bs], dtype=np.uint8).copy()\n"
+        "    for o in range(0, nb * bs - 65536, 7 * 65536): a[o:o + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)\n"
+        "    src = torch.from_numpy(a).cuda(); del a\n"
+        "    for comp in ('lz4', 'lzf'):\n"
+        "        stride = (cw.compress_bound(comp, bs) + 15) // 16 * 16\n"
+        "        dst = torch.zeros(nb * stride, dtype=torch.uint8, device='cuda'); sizes = torch.zeros(nb, dtype=torch.int32, device='cuda')\n"
+        "        for rep in range(2):\n"
+        "            cw.dev_compress(comp, src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s)\n"
+        "        offs = torch.zeros(nb + 1, dtype=torch.int64, device='cuda')\n"
+        "        cw.dev_pack(dst.data_ptr(), stride, sizes.data_ptr(), nb, 0, offs.data_ptr(), s)\n"
+        "        torch.cuda.synchronize()\n"
+        "        total = int(offs[-1].item()); nd = (total + 65535) // 65536\n"
+        "        packed = torch.zeros(nd * 65536, dtype=torch.uint8, device='cuda')\n"
+        "        cw.dev_pack(dst.data_ptr(), stride, sizes.data_ptr(), nb, packed.data_ptr(), offs.data_ptr(), s)\n"
+        "        dig = torch.zeros(nd * 64, dtype=torch.uint8, device='cuda')\n"
+        "        cw.dev_hash('skein512', packed.data_ptr(), 65536, nd, dig.data_ptr(), s)\n"
+        "        torch.cuda.synchronize()\n"
+        "        h = hashlib.sha256(sizes.cpu().numpy().tobytes()); h.update(dig.cpu().numpy().tobytes())\n"
+        "        print('out', comp, bs, total, h.hexdigest(), cw.profile_kernels()['codec'])\n"
+        "        del dst, packed, dig\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({}, {"CW_LZ4_LANES": "0", "CW_LZF_LANES": "0"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+        assert r.returncode == 0, (env, r.stderr[-2000:])
+        outs.append([ln.split(None, 5) for ln in r.stdout.splitlines() if ln.startswith("out ")])
+    assert len(outs[0]) == 4 and len(outs[1]) == 4
+    for a, b in zip(*outs):
+        assert a[:5] == b[:5], (a, b)
+        assert "lanes" in a[5] and "lanes" not in b[5], (a, b)
+    assert "beside" in outs[0][0][5] and "beside" in outs[0][1][5]
