@@ -49,15 +49,49 @@ constexpr uint32_t kInLdsMax = 16384; // blocks up to this size are staged in LD
 constexpr uint32_t kRedo = 0xFFFFFFFFu; // sizes[] marker: exchange kernel -> write/read-back kernel
 
 // Small blocks, large batches: the lane-per-block parser runs BESIDE the link/chain rounds (second stream).  The rounds walk
-// the batch from block 0 upwards, the lanes pull blocks from the top downwards; ctr[1] = blocks the lanes have taken,
-// ctr[2] = blocks the rounds have claimed (raised by a round's first kernel before it touches a block).  A lane pulls only
-// while more than `reserve` (>= two rounds) unclaimed blocks are left, so a block it takes can never be inside a claimed
-// round, and a round's kernels skip the blocks of theirs that the lanes took -- whatever the interleaving, every block is
-// parsed by exactly one side.  share == nullptr: no lanes beside (the rounds take everything).
-struct LaneShare { uint32_t *ctr; size_t round_first, total; };
+// the batch from block 0 upwards, the lanes pull blocks from the top downwards.  ONE 64-bit word holds both frontiers --
+// low half: blocks the lanes have taken, high half: blocks the rounds have claimed -- and both sides move theirs with a
+// compare-and-swap of the whole word: a round's first kernel raises `claimed` to the end of the round before it touches a
+// block and then reads `taken`; a wavefront of lanes takes m blocks only by swapping (claimed, taken) -> (claimed, taken + m)
+// with taken + m + claimed + reserve <= total, i.e. its take is validated against the claim that is current at the instant
+// of the take.  So a taken block is never inside a claimed round, a round sees every take that preceded its claim (and
+// skips those blocks), and later takes lie above its end: whatever the interleaving, every block is parsed by exactly one
+// side.  (A check followed by a separate atomic add is not enough: all lanes of a full grid pass the check at once.)
+// `reserve` is a matter of speed only (the rounds finish the last blocks faster than a lane would).  ctr == nullptr: no
+// lanes beside (the rounds take everything).
+struct LaneShare { uint32_t *ctr; size_t round_first, total; }; // ctr[0]: the round's pull counter; (ctr + 2): the 64-bit word
+__device__ __forceinline__ unsigned long long *share_word(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + 2); }
 __device__ __forceinline__ bool lanes_took(const LaneShare &sh, uint32_t taken, size_t blk)
 {
     return sh.ctr && sh.round_first + blk >= sh.total - taken;
+}
+// a round's claim of blocks [.., end); returns the lanes' `taken` as of the claim
+__device__ __forceinline__ uint32_t share_claim(uint32_t *ctr, uint32_t end)
+{
+    unsigned long long *w = share_word(ctr);
+    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((uint32_t)(old >> 32) < end) {
+        const unsigned long long want = ((unsigned long long)end << 32) | (uint32_t)old;
+        const unsigned long long seen = atomicCAS(w, old, want);
+        if (seen == old) { old = want; break; }
+        old = seen;
+    }
+    return (uint32_t)old;
+}
+// up to m blocks for a wavefront of lanes: returns how many it got and the first of their ranks in `first`
+__device__ __forceinline__ uint32_t share_take(uint32_t *ctr, uint32_t m, size_t total, uint32_t reserve, uint32_t &first)
+{
+    unsigned long long *w = share_word(ctr);
+    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const uint64_t used = (uint64_t)(uint32_t)old + (uint32_t)(old >> 32) + reserve;
+        const uint32_t got = used < total ? (uint32_t)(total - used < m ? total - used : m) : 0u;
+        first = (uint32_t)old;
+        if (!got) return 0;
+        const unsigned long long seen = atomicCAS(w, old, old + got);
+        if (seen == old) return got;
+        old = seen;
+    }
 }
 
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
@@ -431,9 +465,10 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                  uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo, LaneShare share)
 {
     uint32_t taken = 0;
-    if (share.ctr) { // claim this round's blocks, then see what the lanes already hold
-        if (threadIdx.x == 0) atomicMax(&share.ctr[2], (uint32_t)(share.round_first + nblocks));
-        taken = __hip_atomic_load(&share.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (share.ctr) { // claim this round's blocks, then see what the lanes already hold (every lane of every workgroup: same answer
+                     // or a later one, and a later `taken` only covers blocks above this round)
+        taken = share_claim(share.ctr, (uint32_t)(share.round_first + nblocks));
+        taken = __builtin_amdgcn_readfirstlane(taken);
         if (share.round_first >= share.total - taken) return; // the whole round is theirs
     }
     // LDS: the 128 KiB table, then the block (coalesced copy; positions are then read as aligned dwords)
@@ -552,8 +587,9 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                  uint32_t *__restrict__ counter, LaneShare share)
 {
     uint32_t taken = 0;
-    if (share.ctr) {
-        taken = __hip_atomic_load(&share.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (share.ctr) { // (the round is claimed: its links kernel ran)
+        taken = (uint32_t)__hip_atomic_load(share_word(share.ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        taken = __builtin_amdgcn_readfirstlane(taken);
         if (share.round_first >= share.total - taken) return;
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -787,8 +823,7 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     };
     auto tab_put = [&](uint16_t *t, uint32_t slot, uint32_t pos) { t[slot] = (uint16_t)(TAGGED ? (epoch << 12) | pos : pos); };
     // reserve == 0: the lanes take every block, pulled upwards from counter[0].  reserve > 0: beside the link/chain rounds --
-    // blocks are pulled from the top downwards (counter[1]) while more than `reserve` unclaimed blocks are left (counter[2],
-    // see LaneShare)
+    // blocks are taken from the top downwards while more than `reserve` unclaimed blocks are left (LaneShare)
     uint16_t *tab = tables + ((size_t)blockIdx.x * 64 + threadIdx.x) * kLzfSlots;
     const uint32_t cap = n - 1; // out_len of the reference's call (n >= 16 here)
     enum : uint32_t { NEXT = 0, STEP = 1, TAIL = 2, EXIT = 3 };
@@ -800,14 +835,15 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
     while (__ballot(state != EXIT)) {
         if (state == NEXT) {
-            if (reserve) {
-                const uint32_t taken = __hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t claimed = __hip_atomic_load(&counter[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                blk = nblocks; // = nothing
-                if ((size_t)taken + claimed + reserve < nblocks) {
-                    const uint32_t k = atomicAdd(&counter[1], 1u);
-                    if (k < nblocks) blk = nblocks - 1 - k; // pulled means parsed: the rounds skip everything >= nblocks - taken
-                }
+            if (reserve) { // the wavefront's idle lanes ask together (LaneShare): one compare-and-swap for all of them
+                const unsigned long long idle = __ballot(true);
+                const uint32_t m = (uint32_t)__builtin_popcountll(idle), leader = (uint32_t)__builtin_ctzll(idle);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                uint32_t first = 0, got = 0;
+                if (threadIdx.x == leader) got = share_take(counter, m, nblocks, reserve, first);
+                got = __builtin_amdgcn_readlane(got, leader);
+                first = __builtin_amdgcn_readlane(first, leader);
+                blk = rank < got ? nblocks - 1 - ((size_t)first + rank) : nblocks; // taken means parsed: the rounds skip it
             } else {
                 blk = atomicAdd(counter, 1u);
             }

@@ -459,7 +459,7 @@ def test_lane_per_block_decoders():
 
 
 def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
-    """At the sizes where the launch policy itself switches the lane parsers on -- 256 Ki blocks of 4 KiB (lanes BESIDE the
+    """At the sizes where the launch policy itself switches the lane parsers on -- 256 Ki and 64 Ki blocks of 4 KiB (lanes BESIDE the
     LDS-resident parsers, real interleavings of the shared queue / the top-down and bottom-up claims) and 32 Ki blocks of 64 KiB
     (lanes take the queue) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
     (CW_LZ4_LANES=0 CW_LZF_LANES=0), which the parity tests pin to the oracle.  Compared through a Skein-512 digest per 64 KiB of
@@ -472,7 +472,7 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         "s = torch.cuda.current_stream().cuda_stream\n"
         "data = b''.join(corpus_file(n) for n in corpus_names())\n"
         "rng = np.random.default_rng(11)\n"
-        "for bs, nb in ((4096, 262144), (65536, 32768)):\n"
+        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768)):\n"
         "    a = np.frombuffer((data * (nb * bs // len(data) + 1))[:nb * bs], dtype=np.uint8).copy()\n"
         "    for o in range(0, nb * bs - 65536, 7 * 65536): a[o:o + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)\n"
         "    src = torch.from_numpy(a).cuda(); del a\n"
@@ -498,8 +498,10 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
         assert r.returncode == 0, (env, r.stderr[-2000:])
         outs.append([ln.split(None, 5) for ln in r.stdout.splitlines() if ln.startswith("out ")])
-    assert len(outs[0]) == 4 and len(outs[1]) == 4
-    for a, b in zip(*outs):
+    assert len(outs[0]) == 6 and len(outs[1]) == 6
+    for i, (a, b) in enumerate(zip(*outs)):
         assert a[:5] == b[:5], (a, b)
-        assert "lanes" in a[5] and "lanes" not in b[5], (a, b)
-    assert "beside" in outs[0][0][5] and "beside" in outs[0][1][5]
+        # 64 Ki blocks of 4 KiB: as many blocks as a full grid has lanes (every lane asks at once -- the case a check-then-add
+        # protocol got wrong); below LZ4's threshold, above LZF's
+        assert ("lanes" in a[5]) == (i != 2) and "lanes" not in b[5], (a, b)
+    assert "beside" in outs[0][0][5] and "beside" in outs[0][1][5] and "beside" in outs[0][3][5]

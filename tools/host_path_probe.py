@@ -18,6 +18,7 @@ ap.add_argument("--bs", type=int, default=65536)
 ap.add_argument("--hash", default="skein512")
 ap.add_argument("--comp", default="lz4")
 ap.add_argument("--passes", type=int, default=2)
+ap.add_argument("--data", default="random", choices=["random", "corpus"])
 a = ap.parse_args()
 cw.init(0)
 L = cw.lib()
@@ -27,7 +28,19 @@ nb = int(a.gib * (1 << 30)) // a.bs
 cap = nb * cw.compress_bound(a.comp, a.bs)
 hs, hp = L.cw_host_alloc(nb * a.bs), L.cw_host_alloc(cap)
 dev = torch.empty(nb * a.bs, dtype=torch.uint8, device="cuda")
-cw.dev_gen_random(0xC0FFEE, 0, nb, a.bs, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+if a.data == "random":
+    cw.dev_gen_random(0xC0FFEE, 0, nb, a.bs, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+else:  # the in-tree corpora, whole 64 KiB blocks of every file, tiled
+    import glob
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "corpus")
+    parts = []
+    for f in sorted(glob.glob(os.path.join(root, "*", "*"))):
+        b = open(f, "rb").read()
+        parts.append(b[: len(b) // 65536 * 65536])
+    tile = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8).cuda()
+    for o in range(0, nb * a.bs, tile.numel()):
+        k = min(tile.numel(), nb * a.bs - o)
+        dev[o:o + k] = tile[:k]
 torch.cuda.synchronize()
 cw.ops.check(L.cw_dev_download(hs, dev.data_ptr(), nb * a.bs))
 del dev
