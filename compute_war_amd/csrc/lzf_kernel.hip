@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -49,50 +50,64 @@ constexpr uint32_t kInLdsMax = 16384; // blocks up to this size are staged in LD
 constexpr uint32_t kRedo = 0xFFFFFFFFu; // sizes[] marker: exchange kernel -> write/read-back kernel
 
 // Small blocks, large batches: the lane-per-block parser runs BESIDE the link/chain rounds (second stream).  The rounds walk
-// the batch from block 0 upwards, the lanes pull blocks from the top downwards.  ONE 64-bit word holds both frontiers --
-// low half: blocks the lanes have taken, high half: blocks the rounds have claimed -- and both sides move theirs with a
-// compare-and-swap of the whole word: a round's first kernel raises `claimed` to the end of the round before it touches a
-// block and then reads `taken`; a wavefront of lanes takes m blocks only by swapping (claimed, taken) -> (claimed, taken + m)
-// with taken + m + claimed + reserve <= total, i.e. its take is validated against the claim that is current at the instant
-// of the take.  So a taken block is never inside a claimed round, a round sees every take that preceded its claim (and
-// skips those blocks), and later takes lie above its end: whatever the interleaving, every block is parsed by exactly one
-// side.  (A check followed by a separate atomic add is not enough: all lanes of a full grid pass the check at once.)
-// `reserve` is a matter of speed only (the rounds finish the last blocks faster than a lane would).  ctr == nullptr: no
-// lanes beside (the rounds take everything).
-struct LaneShare { uint32_t *ctr; size_t round_first, total; }; // ctr[0]: the round's pull counter; (ctr + 2): the 64-bit word
-__device__ __forceinline__ unsigned long long *share_word(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + 2); }
+// the batch from block 0 upwards, the lanes take blocks from the top downwards.  ONE 64-bit word W holds both frontiers -- low
+// half: ranks the lanes have drawn (rank k is block total-1-k), high half: blocks the rounds have claimed -- and both sides
+// move theirs with ONE fetch-and-add each, so each sees the other's frontier as of the instant of its own move:
+//   * a round's first kernel adds the round's length to `claimed` (rounds run in order over contiguous ranges) before it
+//     touches a block; the value returned is the lanes' `taken` AT THE CLAIM.  Workgroup 0 does it and publishes that number
+//     with the round's sequence number; the other workgroups and the round's chain kernel use the published number.  The
+//     round parses exactly the blocks of its range with rank >= that `taken`.
+//   * a wavefront of lanes adds the number of its idle lanes to `taken`; a drawn rank is the lane's to parse if its block lay
+//     above `claimed` as returned by the same add, and is dropped otherwise.
+// A block drawn before a round's claim is counted in that round's `taken` and skipped by it; a block drawn after the claim
+// is either above the round (kept) or inside a claimed range (dropped -- and its rank is >= the `taken` of the round that
+// owns it, which therefore parses it).  Whatever the interleaving, every block is parsed by exactly one side, with no retry
+// loop anywhere: a compare-and-swap version of this collapsed under its own retries (a thousand wavefronts and the rounds'
+// workgroups on one word: 32 -> 5 GB/s), and a check followed by a separate add let a full grid of lanes pass the check at
+// once and meet the rounds.  `reserve` (how many unclaimed blocks the lanes leave alone) is a matter of speed only.
+// ctr == nullptr: no lanes beside (the rounds take everything).
+// counter block of a stream's workspace (dword indices; each group on a 128-byte line of its own -- they are hammered by different
+// parties): [0] the round's pull counter, [32..33] W, [64] poor, [65] fine, [66] handed back, [96..97] published
+constexpr uint32_t kCtrWord = 32, kCtrPoor = 64, kCtrFine = 65, kCtrHanded = 66, kCtrPublished = 96, kCtrBytes = 512;
+struct LaneShare { uint32_t *ctr; size_t round_first, total; uint32_t seq; };
+__device__ __forceinline__ unsigned long long *share_word(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + kCtrWord); }
+__device__ __forceinline__ unsigned long long *share_published(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + kCtrPublished); }
 __device__ __forceinline__ bool lanes_took(const LaneShare &sh, uint32_t taken, size_t blk)
 {
     return sh.ctr && sh.round_first + blk >= sh.total - taken;
 }
-// a round's claim of blocks [.., end); returns the lanes' `taken` as of the claim
-__device__ __forceinline__ uint32_t share_claim(uint32_t *ctr, uint32_t end)
+// the lanes' `taken` as of this round's claim (claim == true: the round's first kernel; every lane of the grid calls it)
+__device__ __forceinline__ uint32_t share_round_taken(const LaneShare &sh, size_t nblocks, bool claim)
+{
+    unsigned long long *pub = share_published(sh.ctr);
+    if (claim && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long old = atomicAdd(share_word(sh.ctr), (unsigned long long)nblocks << 32);
+        __hip_atomic_store(pub, ((unsigned long long)sh.seq << 32) | (uint32_t)old, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long p = __hip_atomic_load(pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    while ((uint32_t)(p >> 32) != sh.seq) { // (workgroup 0 is dispatched first: it is running)
+        __builtin_amdgcn_s_sleep(2);
+        p = __hip_atomic_load(pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __builtin_amdgcn_readfirstlane((uint32_t)p);
+}
+// m ranks for a wavefront of lanes: returns the first rank and the rounds' `claimed` as of the draw; 0 ranks (first = total)
+// when fewer than m + reserve unclaimed blocks are left
+__device__ __forceinline__ void share_take(uint32_t *ctr, uint32_t m, size_t total, uint32_t reserve, uint32_t &first, uint32_t &claimed)
 {
     unsigned long long *w = share_word(ctr);
-    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((uint32_t)(old >> 32) < end) {
-        const unsigned long long want = ((unsigned long long)end << 32) | (uint32_t)old;
-        const unsigned long long seen = atomicCAS(w, old, want);
-        if (seen == old) { old = want; break; }
-        old = seen;
-    }
-    return (uint32_t)old;
+    const unsigned long long seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    first = (uint32_t)total; claimed = 0;
+    if ((uint64_t)(uint32_t)seen + (uint32_t)(seen >> 32) + reserve + m > total) return;
+    const unsigned long long old = atomicAdd(w, (unsigned long long)m);
+    first = (uint32_t)old; claimed = (uint32_t)(old >> 32);
 }
-// up to m blocks for a wavefront of lanes: returns how many it got and the first of their ranks in `first`
-__device__ __forceinline__ uint32_t share_take(uint32_t *ctr, uint32_t m, size_t total, uint32_t reserve, uint32_t &first)
-{
-    unsigned long long *w = share_word(ctr);
-    unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        const uint64_t used = (uint64_t)(uint32_t)old + (uint32_t)(old >> 32) + reserve;
-        const uint32_t got = used < total ? (uint32_t)(total - used < m ? total - used : m) : 0u;
-        first = (uint32_t)old;
-        if (!got) return 0;
-        const unsigned long long seen = atomicCAS(w, old, old + got);
-        if (seen == old) return got;
-        old = seen;
-    }
-}
+
+// A round of the link/chain kernels over listed blocks (those the lanes handed back) instead of a contiguous range
+struct BlockList {
+    const uint32_t *queue, *count; uint32_t first;
+    __device__ __forceinline__ size_t at(size_t blk) const { return queue ? queue[first + blk] : blk; }
+};
 
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 __device__ __forceinline__ uint32_t lzf_slot(uint32_t b0, uint32_t b1, uint32_t b2)
@@ -462,13 +477,16 @@ __device__ __forceinline__ uint32_t load3(const uint8_t *g, uint32_t n, uint32_t
 
 __global__ void __launch_bounds__(64)
 lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint16_t *__restrict__ links,
-                 uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo, LaneShare share)
+                 uint32_t n2, uint32_t *__restrict__ sizes, uint32_t force_redo, LaneShare share, BlockList list)
 {
+    if (list.queue) { // a round over handed-back blocks: entries [list.first, list.first + nblocks) of the queue, as far as it is filled
+        const uint32_t cnt = *list.count;
+        if (list.first >= cnt) return;
+        if (nblocks > cnt - list.first) nblocks = cnt - list.first;
+    }
     uint32_t taken = 0;
-    if (share.ctr) { // claim this round's blocks, then see what the lanes already hold (every lane of every workgroup: same answer
-                     // or a later one, and a later `taken` only covers blocks above this round)
-        taken = share_claim(share.ctr, (uint32_t)(share.round_first + nblocks));
-        taken = __builtin_amdgcn_readfirstlane(taken);
+    if (share.ctr) { // claim this round's blocks and learn what the lanes held at that instant
+        taken = share_round_taken(share, nblocks, true);
         if (share.round_first >= share.total - taken) return; // the whole round is theirs
     }
     // LDS: the 128 KiB table, then the block (coalesced copy; positions are then read as aligned dwords)
@@ -486,7 +504,7 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 #define CW_PREFETCH(BLK)                                                                                   \
     do {                                                                                                   \
         const size_t b_ = (BLK) < nblocks ? (BLK) : nblocks - 1;                                           \
-        const uint4 *g4 = reinterpret_cast<const uint4 *>(src + b_ * src_stride);                          \
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(src + list.at(b_) * src_stride);                 \
         const uint32_t last_ = (n - 1) / 16;                                                               \
         CW_PRE1(0, g4, last_) CW_PRE1(1, g4, last_) CW_PRE1(2, g4, last_) CW_PRE1(3, g4, last_)            \
         CW_PRE1(4, g4, last_) CW_PRE1(5, g4, last_) CW_PRE1(6, g4, last_) CW_PRE1(7, g4, last_)            \
@@ -499,7 +517,8 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             if (vec) CW_PREFETCH(blk + gridDim.x);
             continue;
         }
-        const uint8_t *g = src + blk * src_stride;
+        const size_t gb = list.at(blk); // the block's index in src / sizes (links are per round)
+        const uint8_t *g = src + gb * src_stride;
         uint16_t *out = links + blk * (size_t)n2;
         __syncthreads();
 #pragma unroll 16
@@ -570,7 +589,7 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 }
             }
         }
-        if (lane == 0) sizes[blk] = bad ? kRedo : 0u; // 0 = "links are valid" for lzf_chain_kernel
+        if (lane == 0) sizes[gb] = bad ? kRedo : 0u; // 0 = "links are valid" for lzf_chain_kernel
     }
 #undef CW_PREFETCH
 #undef CW_PRE1
@@ -584,12 +603,16 @@ template <bool BIG>
 __global__ void __launch_bounds__(64)
 lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst,
                  size_t dst_stride, uint32_t *__restrict__ sizes, uint16_t *__restrict__ links, uint32_t n2,
-                 uint32_t *__restrict__ counter, LaneShare share)
+                 uint32_t *__restrict__ counter, LaneShare share, BlockList list)
 {
+    if (list.queue) {
+        const uint32_t cnt = *list.count;
+        if (list.first >= cnt) return;
+        if (nblocks > cnt - list.first) nblocks = cnt - list.first;
+    }
     uint32_t taken = 0;
-    if (share.ctr) { // (the round is claimed: its links kernel ran)
-        taken = (uint32_t)__hip_atomic_load(share_word(share.ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        taken = __builtin_amdgcn_readfirstlane(taken);
+    if (share.ctr) { // (the round is claimed: its links kernel ran and published)
+        taken = share_round_taken(share, nblocks, false);
         if (share.round_first >= share.total - taken) return;
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -608,9 +631,10 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
         const size_t blk = __builtin_amdgcn_readfirstlane(mailbox);
         if (blk >= nblocks) break;
         if (lanes_took(share, taken, blk)) continue;                       // a lane parses (or parsed) it
-        if (__builtin_amdgcn_readfirstlane(sizes[blk]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
-        const uint8_t *g = src + blk * src_stride;
-        uint8_t *out = dst + blk * dst_stride;
+        const size_t gb = list.at(blk);
+        if (__builtin_amdgcn_readfirstlane(sizes[gb]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
+        const uint8_t *g = src + gb * src_stride;
+        uint8_t *out = dst + gb * dst_stride;
         uint16_t *lk = links + blk * (size_t)n2;
         if (BIG) {
             for (uint32_t i = lane; i < n2 / 32; i += 64) skipmap[i] = 0;
@@ -785,7 +809,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 else op -= 1;
             }
         }
-        if (lane == 0) sizes[blk] = fail ? 0u : op;
+        if (lane == 0) sizes[gb] = fail ? 0u : op;
     }
 }
 
@@ -798,8 +822,10 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kLzfLaneMinBlocks = 24576;
 constexpr uint32_t kLzfLaneMinSmall = 49152;  // blocks <= 4 KiB: lanes beside the rounds from 48 Ki blocks on (64 Ki: 19.1 vs 13.8 GB/s)
-constexpr size_t kLzfBesideRound = 8192;      // ... in rounds of 8 Ki blocks, the last two rounds' worth left to the rounds (LaneShare):
-                                              // 4 KiB text, 1 Mi blocks: 32.2 GB/s; rounds of 32 Ki blocks (reserve 80 Ki) 28.4; of 4 Ki 29.9
+constexpr size_t kLzfBesideRound = 16384;     // ... in rounds of 16 Ki blocks, the last 16 Ki unclaimed blocks left to the rounds.  4 KiB blocks, text /
+                                              // 50 % noise / noise, GB/s -- 1 Mi blocks: rounds of 8 Ki 29.8 / 24.7 / 52.9, 16 Ki 33.1 / 29.0 / 57.7,
+                                              // 32 Ki 32.6 / 30.9 / 59.2; 96 Ki blocks: 25.6 / 36.3 / 50.5, 26.2 / 39.3 / 53.6, 23.1 / 36.4 / 55.0
+constexpr uint32_t kLzfBesideReserve = 16384;
 
 // 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
 __device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32_t n)
@@ -814,8 +840,27 @@ __device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32
 template <bool TAGGED>
 __global__ void __launch_bounds__(64)
 lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst, size_t dst_stride,
-                 uint32_t *__restrict__ sizes, uint16_t *__restrict__ tables, uint32_t *__restrict__ counter, uint32_t reserve)
+                 uint32_t *__restrict__ sizes, uint16_t *__restrict__ tables, uint32_t *__restrict__ counter, uint32_t reserve,
+                 uint32_t *__restrict__ handback)
 {
+    // Blocks that do not compress are the lanes' worst case and the chain parser's best (a noise block is a serial walk of all
+    // its positions here -- 61 -> 18 GB/s on random 64 KiB blocks when the lanes took them all -- and a 60 GB/s bail-out there).
+    // So a lane looks at its block once, after `check_at` positions: less than 1/32 saved so far => the block goes to the
+    // hand-back list (counter[kCtrHanded] entries), which the link/chain kernels parse after the lanes are done; and once more than a
+    // third of the blocks looked at were such (counter[kCtrPoor], counter[kCtrFine]), the lanes stop parsing: beside the rounds they
+    // take no more blocks, on their own they pass what is left straight to the list.
+    const uint32_t check_at = n >= 2048 ? 512u : n / 4 < 128 ? 128u : n / 4;
+    bool checked = false;
+    // Slow start: the first 128 workgroups sample the batch; the others wait (bounded: ~3 ms) until 512 blocks have been looked at
+    // and then start -- or, on noise, leave at once.  (Random 4 KiB blocks beside the rounds: 65,536 first looks cost 11 ms.)
+    if (blockIdx.x >= 128) {
+        for (uint32_t spin = 0; spin < 4096; spin++) {
+            const uint32_t seen = __hip_atomic_load(&counter[kCtrPoor], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                                  __hip_atomic_load(&counter[kCtrFine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen >= 512) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
     uint32_t epoch = 15; // TAGGED: forces a clean table before the first block
     auto tab_get = [&](uint16_t *t, uint32_t slot) -> uint32_t {
         const uint32_t e = t[slot];
@@ -835,21 +880,33 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
     while (__ballot(state != EXIT)) {
         if (state == NEXT) {
-            if (reserve) { // the wavefront's idle lanes ask together (LaneShare): one compare-and-swap for all of them
+            const uint32_t poor = __hip_atomic_load(&counter[kCtrPoor], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t fine = __hip_atomic_load(&counter[kCtrFine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (beside the rounds the lanes also slow THEM down, so they give up sooner: a fifth of noise against a third)
+            const bool noisy = reserve ? poor > 64 + fine / 4 : poor > 32 + fine / 2;
+            if (reserve && noisy) {
+                blk = nblocks; // the rounds take the rest
+            } else if (reserve) { // the wavefront's idle lanes ask together (LaneShare): one compare-and-swap for all of them
                 const unsigned long long idle = __ballot(true);
                 const uint32_t m = (uint32_t)__builtin_popcountll(idle), leader = (uint32_t)__builtin_ctzll(idle);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                uint32_t first = 0, got = 0;
-                if (threadIdx.x == leader) got = share_take(counter, m, nblocks, reserve, first);
-                got = __builtin_amdgcn_readlane(got, leader);
+                uint32_t first = 0, claimed = 0;
+                if (threadIdx.x == leader) share_take(counter, m, nblocks, reserve, first, claimed);
                 first = __builtin_amdgcn_readlane(first, leader);
-                blk = rank < got ? nblocks - 1 - ((size_t)first + rank) : nblocks; // taken means parsed: the rounds skip it
+                claimed = __builtin_amdgcn_readlane(claimed, leader);
+                const size_t k = (size_t)first + rank; // my rank, if any: block nblocks-1-k, mine if it lay above `claimed` at the draw
+                blk = k < nblocks && nblocks - 1 - k >= claimed ? nblocks - 1 - k : nblocks;
             } else {
                 blk = atomicAdd(counter, 1u);
+                while (noisy && blk < nblocks) { // unparsed, to the list
+                    handback[atomicAdd(&counter[kCtrHanded], 1u)] = (uint32_t)blk;
+                    blk = atomicAdd(counter, 1u);
+                }
             }
             if (blk >= nblocks) {
                 state = EXIT;
             } else {
+                checked = false;
                 g = src + blk * src_stride;
                 out = dst + blk * dst_stride;
                 if (!TAGGED || ++epoch == 16) {
@@ -860,6 +917,17 @@ lzf_lanes_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 ip = 0; op = 1; lit = 0; fail = false; // op = 1: the first literal run's control byte is reserved
                 v = lzf_rd(g, 0, n);
                 state = STEP;
+            }
+        }
+
+        if (state == STEP && !checked && ip >= check_at) {
+            checked = true;
+            if (op + (ip >> 5) >= ip) { // (what the lane wrote so far is overwritten by the chain parser)
+                atomicAdd(&counter[kCtrPoor], 1u);
+                handback[atomicAdd(&counter[kCtrHanded], 1u)] = (uint32_t)blk;
+                state = NEXT;
+            } else {
+                atomicAdd(&counter[kCtrFine], 1u);
             }
         }
 
@@ -959,6 +1027,7 @@ namespace {
 struct LinkSpace {
     uint16_t *p = nullptr; size_t cap = 0; uint32_t *counter = nullptr;
     uint16_t *lane_tabs = nullptr; size_t lane_cap = 0; // tables of the lane-per-block parser: 128 KiB per lane
+    uint32_t *handback = nullptr; size_t hb_cap = 0;    // blocks the lanes passed on to the link/chain kernels
     hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; // the lane parser's stream beside the rounds
 };
 struct LinkEntry { LinkSpace s; std::mutex launch; };
@@ -973,6 +1042,7 @@ void lzf_release_workspaces()
         if (kv.second.s.p) (void)hipFree(kv.second.s.p);
         if (kv.second.s.counter) (void)hipFree(kv.second.s.counter);
         if (kv.second.s.lane_tabs) (void)hipFree(kv.second.s.lane_tabs);
+        if (kv.second.s.handback) (void)hipFree(kv.second.s.handback);
         if (kv.second.s.side) { (void)hipStreamDestroy(kv.second.s.side); (void)hipEventDestroy(kv.second.s.fork); (void)hipEventDestroy(kv.second.s.join); }
     }
     link_map.clear();
@@ -1033,13 +1103,28 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         // pulling from the top of the batch while the rounds climb from the bottom (LaneShare) -- one side is bound by LDS
         // capacity and chain latency, the other by random memory accesses.
         uint32_t lane_reserve = 0;
+        const size_t round_max = ws_bytes / (2 * (size_t)n2); // blocks per round that the link workspace admits
+        const size_t hb_chunk = nblocks < round_max ? nblocks : round_max; // rounds of the hand-back pass
+        hipError_t e;
+        {
+            LinkSpace &w = entry->s;
+            const size_t need = use_lanes && hb_chunk > chunk ? hb_chunk : chunk;
+            if (w.cap < need * n2) {
+                if (w.p) { e = hipFree(w.p); if (e != hipSuccess) return e; }
+                w.p = nullptr; w.cap = 0;
+                e = hipMalloc(reinterpret_cast<void **>(&w.p), need * n2 * sizeof(uint16_t));
+                if (e != hipSuccess) return e;
+                w.cap = need * n2;
+            }
+            if (!w.counter && (e = hipMalloc(reinterpret_cast<void **>(&w.counter), kCtrBytes)) != hipSuccess) return e;
+        }
         if (use_lanes) {
             static const char *lw_env = getenv("CW_LANES_WPC");
             const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 4;
             size_t lgrid = (nblocks + 63) / 64;
             if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
+            if (beside && lgrid * 64 + kLzfBesideReserve > nblocks) lgrid = nblocks > kLzfBesideReserve + 64 ? (nblocks - kLzfBesideReserve) / 64 : 1; // (no lane without a block)
             LinkSpace &w = entry->s;
-            hipError_t e;
             if (w.lane_cap < lgrid * 64) {
                 if (w.lane_tabs) { e = hipFree(w.lane_tabs); if (e != hipSuccess) return e; }
                 w.lane_tabs = nullptr; w.lane_cap = 0;
@@ -1047,55 +1132,41 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 if (e != hipSuccess) return e;
                 w.lane_cap = lgrid * 64;
             }
-            if (!w.counter && (e = hipMalloc(reinterpret_cast<void **>(&w.counter), 64)) != hipSuccess) return e;
-            if ((e = hipMemsetAsync(w.counter, 0, 16, stream)) != hipSuccess) return e;
-            if (!beside) {
-                if (n <= 4096)
-                    hipLaunchKernelGGL(lzf_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride,
-                                       sizes, w.lane_tabs, w.counter, 0u);
-                else
-                    hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst, dst_stride,
-                                       sizes, w.lane_tabs, w.counter, 0u);
-                note_kernels(0, n <= 4096 ? "cw::lzf_lanes_kernel<true>" : "cw::lzf_lanes_kernel<false>");
-                return hipGetLastError();
+            if (w.hb_cap < nblocks) { // a block is handed back once at most
+                if (w.handback) { e = hipFree(w.handback); if (e != hipSuccess) return e; }
+                w.handback = nullptr; w.hb_cap = 0;
+                e = hipMalloc(reinterpret_cast<void **>(&w.handback), nblocks * sizeof(uint32_t));
+                if (e != hipSuccess) return e;
+                w.hb_cap = nblocks;
             }
-            if (!w.side) {
-                if ((e = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking)) != hipSuccess) return e;
-                if ((e = hipEventCreateWithFlags(&w.fork, hipEventDisableTiming)) != hipSuccess) return e;
-                if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(w.counter, 0, kCtrBytes, stream)) != hipSuccess) return e;
+            hipStream_t lstream = stream;
+            if (beside) {
+                if (!w.side) {
+                    if ((e = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking)) != hipSuccess) return e;
+                    if ((e = hipEventCreateWithFlags(&w.fork, hipEventDisableTiming)) != hipSuccess) return e;
+                    if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
+                }
+                static const char *rs_env = getenv("CW_LANES_RESERVE");
+                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : kLzfBesideReserve;
+                if (lane_reserve < 1) lane_reserve = 1; // (0 means "on their own" to the kernel; the protocol itself needs no reserve)
+                if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;
+                lstream = w.side;
             }
-            static const char *rs_env = getenv("CW_LANES_RESERVE");
-            lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (uint32_t)(2 * chunk);
-            if (lane_reserve < 2 * chunk) lane_reserve = (uint32_t)(2 * chunk); // never inside a claimed round (LaneShare)
-            if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;
             if (n <= 4096)
-                hipLaunchKernelGGL(lzf_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, w.side, src, n, src_stride, nblocks, dst, dst_stride,
-                                   sizes, w.lane_tabs, w.counter, lane_reserve);
+                hipLaunchKernelGGL(lzf_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, lstream, src, n, src_stride, nblocks, dst, dst_stride,
+                                   sizes, w.lane_tabs, w.counter, lane_reserve, w.handback);
             else
-                hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, w.side, src, n, src_stride, nblocks, dst, dst_stride,
-                                   sizes, w.lane_tabs, w.counter, lane_reserve);
+                hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, lstream, src, n, src_stride, nblocks, dst, dst_stride,
+                                   sizes, w.lane_tabs, w.counter, lane_reserve, w.handback);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        {
-            LinkSpace &w = entry->s;
-            if (w.cap < chunk * n2) {
-                if (w.p) { hipError_t e = hipFree(w.p); if (e != hipSuccess) return e; }
-                w.p = nullptr; w.cap = 0;
-                hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.p), chunk * n2 * sizeof(uint16_t));
-                if (e != hipSuccess) return e;
-                w.cap = chunk * n2;
-            }
-            if (!w.counter) {
-                hipError_t e = hipMalloc(reinterpret_cast<void **>(&w.counter), 64);
-                if (e != hipSuccess) return e;
-            }
-            ls = w;
-        }
+        ls = entry->s;
         static bool chain_attr = false;
         if (!chain_attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_links_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kChainMax + 48);
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_links_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLzfTabBytes + kChainMax + 48);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lzf_chain_kernel<false>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kChainMax + 256);
             if (e != hipSuccess) return e;
@@ -1105,33 +1176,51 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const uint32_t chain_lds = big ? n2 / 8 + 16u : 2 * n2 + ((n + 15u) & ~15u) + 16u;
         size_t per_cu = (160u * 1024u) / (chain_lds + 64);
         if (per_cu > (big ? 20u : 16u)) per_cu = big ? 20 : 16;
-        for (size_t first = 0; first < nblocks; first += chunk) {
-            const size_t nb = nblocks - first < chunk ? nblocks - first : chunk;
-            const uint8_t *s0 = src + first * src_stride;
-            hipError_t e = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
-            if (e != hipSuccess) return e;
-            const LaneShare share = {beside ? ls.counter : nullptr, first, nblocks};
-            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, s0, n, src_stride,
-                               nb, ls.p, n2, sizes + first, force_redo, share);
+        // one round of the link + chain kernels: blocks [first, first + nb) of the batch, or entries [first, first + nb) of the
+        // hand-back list (as far as the lanes filled it: the kernels read its length on the device and return at once beyond it)
+        auto round = [&](size_t first, size_t nb, bool listed) -> hipError_t {
+            hipError_t r = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
+            if (r != hipSuccess) return r;
+            const LaneShare share = {beside && !listed ? ls.counter : nullptr, first, nblocks, (uint32_t)(first / chunk + 1)};
+            const BlockList list = {listed ? ls.handback : nullptr, listed ? ls.counter + kCtrHanded : nullptr, (uint32_t)first};
+            const size_t off = listed ? 0 : first; // listed blocks are addressed through the list, from the batch's base
+            hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, src + off * src_stride, n,
+                               src_stride, nb, ls.p, n2, sizes + off, force_redo, share, list);
             const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
             if (big)
-                hipLaunchKernelGGL(lzf_chain_kernel<true>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
-                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter, share);
+                hipLaunchKernelGGL(lzf_chain_kernel<true>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, src + off * src_stride, n, src_stride,
+                                   nb, dst + off * dst_stride, dst_stride, sizes + off, ls.p, n2, ls.counter, share, list);
             else
-                hipLaunchKernelGGL(lzf_chain_kernel<false>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, s0, n, src_stride, nb,
-                                   dst + first * dst_stride, dst_stride, sizes + first, ls.p, n2, ls.counter, share);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (beside) { // the redo pass and the caller's later work wait for the lanes too
-            hipError_t e = hipEventRecord(ls.join, ls.side);
+                hipLaunchKernelGGL(lzf_chain_kernel<false>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, src + off * src_stride, n, src_stride,
+                                   nb, dst + off * dst_stride, dst_stride, sizes + off, ls.p, n2, ls.counter, share, list);
+            return hipGetLastError();
+        };
+        if (!use_lanes || beside)
+            for (size_t first = 0; first < nblocks; first += chunk)
+                if ((e = round(first, nblocks - first < chunk ? nblocks - first : chunk, false)) != hipSuccess) return e;
+        if (beside) { // the hand-back pass, the redo pass and the caller's later work wait for the lanes
+            e = hipEventRecord(ls.join, ls.side);
             if (e == hipSuccess) e = hipStreamWaitEvent(stream, ls.join, 0);
             if (e != hipSuccess) return e;
         }
+        if (use_lanes && getenv("CW_DEBUG_LZF")) {
+            uint32_t h[kCtrBytes / 4];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h, ls.counter, kCtrBytes, hipMemcpyDeviceToHost);
+            fprintf(stderr, "lzf lanes: taken %u claimed %u poor %u fine %u handed back %u of %zu\n", h[kCtrWord], h[kCtrWord + 1], h[kCtrPoor],
+                    h[kCtrFine], h[kCtrHanded], nblocks);
+        }
+        if (use_lanes)
+            for (size_t first = 0; first < nblocks; first += hb_chunk)
+                if ((e = round(first, nblocks - first < hb_chunk ? nblocks - first : hb_chunk, true)) != hipSuccess) return e;
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, in_lds, 1u);
         note_kernels(0, beside ? (big ? "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<true>"
                                       : n <= 4096 ? "cw::lzf_lanes_kernel<true> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>"
                                                   : "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>")
+                               : use_lanes ? (n <= 4096 ? "cw::lzf_lanes_kernel<true>, then cw::lzf_links_kernel + cw::lzf_chain_kernel<false> on what it passed on"
+                                              : big ? "cw::lzf_lanes_kernel<false>, then cw::lzf_links_kernel + cw::lzf_chain_kernel<true> on what it passed on"
+                                                    : "cw::lzf_lanes_kernel<false>, then cw::lzf_links_kernel + cw::lzf_chain_kernel<false> on what it passed on")
                                : big ? "cw::lzf_links_kernel + cw::lzf_chain_kernel<true>" : "cw::lzf_links_kernel + cw::lzf_chain_kernel<false>");
         return hipGetLastError();
     }
