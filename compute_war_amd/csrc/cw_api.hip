@@ -716,7 +716,10 @@ void pipe_drain(ThreadCtx &c)
 size_t pipeline_chunk(size_t bb, size_t nblocks)
 {
     static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
-    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (bb > 16384 ? (size_t)512 << 20 : (size_t)64 << 20);
+    // 512 MiB: the chunk's kernels cost 8-10 ms whatever its size and do not overlap across chunks, and a chunk of 4 KiB blocks has
+    // to be large enough for the lane parsers to run beside the LDS-resident ones (8 GiB of 4 KiB corpus blocks, Skein-256 + LZ4 /
+    // SHA-256 + LZF: chunks of 64 MiB 29.5 / 18.8 GB/s, 512 MiB 38.6 / 27.2, 1 GiB 40.0 / 20.8; random data 47 -> 45-47 GB/s)
+    size_t chunk_bytes = ck_env && atol(ck_env) > 0 ? (size_t)atol(ck_env) << 20 : (size_t)512 << 20;
     size_t chunk = chunk_bytes / (bb ? bb : 1);
     if (chunk == 0) chunk = 1;
     if (chunk > nblocks) chunk = nblocks;
