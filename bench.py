@@ -316,6 +316,35 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
         roundtrip = {"blocks_decoded_and_compared": nb - raw, "stored_raw": raw, "ok": True, "seconds": round(time.perf_counter() - t_rt, 2),
                      "how": "cw_dev_decompress of every slot on the device, compared with the input block"}
 
+    # the lane-per-block LZ4 parser is bound by the random memory lines of its probes: its probe rate against what
+    # tools/random_line.hip measured the chip to retire for such a mix.  Probes and sequences per block are counted on the host
+    # (tools/lz_probe_count.py, a pure-Python walk of the parser) over a few sampled blocks.
+    line_roof = None
+    rl = os.path.join(ROOT, "profiles", "random_line.json")
+    if rank == 0 and comp_name == "lz4" and bs > 4096 and kind != "random" and "lanes" in names["codec"] and os.path.exists(rl):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("lz_probe_count", os.path.join(ROOT, "tools", "lz_probe_count.py"))
+        lpc = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(lpc)
+        picks = [(i * nb // 24 + i) % nb for i in range(24)]   # (+ i: both parities of the synthetic mix)
+        stats = [lpc.lz4_counts(src[i * bs:(i + 1) * bs].cpu().numpy().tobytes()) for i in picks]
+        parsed = [(p, q) for p, q, _ in stats if q > 0]          # blocks without a match never reach the parser (the scan writes them)
+        if parsed:
+            probes = sum(p for p, _ in parsed) / len(parsed)
+            seqs = sum(q for _, q in parsed) / len(parsed)
+            lines_per_probe = (2 * probes + 2 * seqs) / probes     # entry load + store per probe; per sequence the ip-2 store and the match's candidate
+            blocks_per_s = nb * len(parsed) / len(stats) / (k_ms["comp"] / 1e3)
+            pts = sorted(json.load(open(rl))["points"], key=lambda q: q["lines_per_probe"])
+            x0, x1 = pts[0]["lines_per_probe"], pts[-1]["lines_per_probe"]
+            y0, y1 = x0 * pts[0]["probes_per_s"], x1 * pts[-1]["probes_per_s"]   # lines per second at both mixes
+            t = min(1.0, max(0.0, (lines_per_probe - x0) / (x1 - x0)))
+            peak_lines = y0 + t * (y1 - y0)
+            got_lines = blocks_per_s * probes * lines_per_probe
+            line_roof = {"bound": "random memory lines (lane-per-block parser)", "achieved": round(got_lines / 1e9, 2), "peak": round(peak_lines / 1e9, 2),
+                         "unit": "G lines/s", "frac": round(got_lines / peak_lines, 4), "probes_per_block": round(probes),
+                         "sequences_per_block": round(seqs), "blocks_sampled": len(stats), "blocks_parsed_share": round(len(parsed) / len(stats), 3),
+                         "source": "profiles/random_line.json (tools/random_line.hip); counts: tools/lz_probe_count.py; time: the codec's whole call"}
+
     if rank != 0:
         return None, None
     csize = bytes_out / total_blocks
@@ -348,6 +377,8 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
     }
     if roundtrip:
         leg["roundtrip"] = roundtrip
+    if line_roof:
+        leg["line_roofline"] = line_roof
     if per_corpus:
         leg["corpus_ratios"] = per_corpus
     if solo_ms:
