@@ -427,7 +427,7 @@ def host_path_leg(cw, torch, hash_name, comp_name, bs, nbytes):
         return {"entry_point": "cw_hash_and_compress_packed (pinned input and output, three-stage pipeline, one calling thread)",
                 "workload": f"{hash_name}+{comp_name} over {nb} x {bs} B uniform-random blocks in host memory",
                 "value": round(nb * bs / t / 1e9, 2), "unit": "GB/s", "seconds": round(t, 4), "bytes_in": nb * bs, "bytes_out": out_bytes,
-                "first_pass_GBps": round(nb * bs / times[0] / 1e9, 2),   # the device's first touch of freshly pinned pages is slower
+                "first_pass_GBps": round(nb * bs / times[0] / 1e9, 2),   # the first pass after idle is slower (clocks, link; not page mapping: DESIGN.md 5)
                 "roofline": {"bound": "pcie", "achieved": round(max(nb * bs, out_bytes) / t / 1e9, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                              "frac": round(max(nb * bs, out_bytes) / t / 1e9 / PCIE_PEAK_GBS, 4),
                              "note": "the busier direction's bytes / time against one direction of PCIe Gen5 x16"}}
