@@ -151,7 +151,7 @@ static void *worker(void *arg)
     const size_t db = cw_digest_bytes(hash_alg);
     const size_t bound = cw_compress_bound(comp_alg, block_size);
     /* offload path: a span of units per call keeps the device's pipeline busy; slot path: one unit, like the reference */
-    size_t span = gpu_offload ? ((size_t)(block_size > 16384 ? 4 : 1) << 30) / unit_bytes : 1; /* 8+ chunks of the library's pipeline per call */
+    size_t span = gpu_offload ? ((size_t)8 << 30) / unit_bytes : 1; /* 16 chunks of the library's pipeline per call: its fill and drain (~25 ms) once per 8 GiB */
     if (span == 0) span = 1;
     const size_t span_blocks = span * (size_t)read_block_factor;
     if (cw_set_device(dev) != CW_OK) { fprintf(stderr, "libcwhc: %s\n", cw_last_error()); exit(2); }

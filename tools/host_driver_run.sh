@@ -19,8 +19,8 @@ with open(os.path.join(d, "corpus4g"), "wb") as f:
     while n < (4 << 30):
         f.write(tile); n += len(tile)
 PY
-for cfg in "random16g 1 skein512 lz4 65536" "random16g 2 skein512 lz4 65536" "random16g 2 skein lz4 4096" "random16g 2 sha256mb lzf 4096" \
-           "corpus4g 1 skein512 lz4 65536" "corpus4g 2 skein512 lz4 65536" "corpus4g 2 skein lz4 4096" "corpus4g 2 sha256mb lzf 4096"; do
+for cfg in "random16g 1 skein512 lz4 65536" "random16g 2 skein512 lz4 65536" "random16g 1 skein lz4 4096" "random16g 1 sha256mb lzf 4096" \
+           "corpus4g 1 skein512 lz4 65536" "corpus4g 1 skein lz4 4096" "corpus4g 1 sha256mb lzf 4096"; do
   set -- $cfg
   echo "== $1 -c $2 $3+$4 $5 B blocks"
   $EXE -v --gpu-offload=true --c-threads=$2 --block-size=$5 --hash-alg=$3 --comp-alg=$4 $D/$1
