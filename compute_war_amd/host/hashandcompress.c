@@ -259,6 +259,10 @@ int main(int argc, char **argv)
         usage(argv[0], "threads and read-blocks must be >= 1, block-size in 1..65536");
     if (n_devices < 1 || n_devices > MAX_DEVICES) usage(argv[0], "devices must be 1..16");
     if (n_threads < n_devices) n_threads = n_devices; /* every device needs a worker */
+    /* --c-threads counts the reference's compute threads.  With the work on the device a worker only feeds one pipeline (three
+     * 512 MiB slots of device memory, an 8.6 GiB page-locked output span), and a second pipeline on the same device shares the same
+     * link: 38.9 GB/s with one worker, 27.1 with two.  run_tests' -c 14 therefore means 14 workers only on the CPU path. */
+    if (gpu_offload && n_threads > n_devices && !getenv("CW_DRIVER_ALL_THREADS")) n_threads = n_devices; /* (the variable: tests of the worker logic) */
 
     for (int g = 0; g < n_devices; g++)
         if (cw_init(g) != CW_OK) { /* initializeGpu() (:95-98), per device; there is no CPU path to fall back to */

@@ -27,7 +27,7 @@ def build_sanitizer_binaries():
 
 
 def _run(exe, args, devices=1):
-    r = subprocess.run([os.path.join(B, exe)] + args, capture_output=True, text=True, timeout=600, env={**ENV, "CW_STUB_DEVICES": str(devices)})
+    r = subprocess.run([os.path.join(B, exe)] + args, capture_output=True, text=True, timeout=600, env={**ENV, "CW_STUB_DEVICES": str(devices), "CW_DRIVER_ALL_THREADS": "1"})
     assert r.returncode == 0, (exe, r.stdout[-1000:], r.stderr[-3000:])
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     return r.stdout.strip().splitlines()
