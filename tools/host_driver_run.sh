@@ -23,5 +23,6 @@ for cfg in "random16g 1 skein512 lz4 65536" "random16g 2 skein512 lz4 65536" "ra
            "corpus4g 1 skein512 lz4 65536" "corpus4g 1 skein lz4 4096" "corpus4g 1 sha256mb lzf 4096"; do
   set -- $cfg
   echo "== $1 -c $2 $3+$4 $5 B blocks"
-  $EXE -v --gpu-offload=true --c-threads=$2 --block-size=$5 --hash-alg=$3 --comp-alg=$4 $D/$1
+  # (CW_DRIVER_ALL_THREADS: the driver otherwise runs ONE worker per device on the offload path whatever -c says)
+  CW_DRIVER_ALL_THREADS=1 $EXE -v --gpu-offload=true --c-threads=$2 --block-size=$5 --hash-alg=$3 --comp-alg=$4 $D/$1
 done
