@@ -167,7 +167,8 @@ hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stri
     if (nblocks == 0) return hipSuccess;
     const dim3 grid((unsigned)((nblocks + CW_SKEIN_THREADS - 1) / CW_SKEIN_THREADS)), block(CW_SKEIN_THREADS);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
-    const bool ragged = (block_bytes % 64) != 0;
+    // (an empty message is "ragged" too: its only chunk is the padding, and the hot path's first load would read 64 bytes that are not there)
+    const bool ragged = block_bytes == 0 || (block_bytes % 64) != 0;
 #define CW_LAUNCH(A, R) hipLaunchKernelGGL((sha256_blocks_kernel<A, R>), grid, block, 0, stream, src, block_bytes, src_stride, nblocks, digests)
     if (aligned && !ragged) CW_LAUNCH(true, false);
     else if (aligned) CW_LAUNCH(true, true);

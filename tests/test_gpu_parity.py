@@ -80,6 +80,18 @@ def test_hash_empty_message(cw, oracle):
     torch.cuda.synchronize()
     assert dig.cpu().numpy()[:64].tobytes() == oracle.skein512(b"", 512)
     assert dig.cpu().numpy()[128:192].tobytes() == oracle.skein512(b"", 512)
+    # every algorithm, many blocks, stride 0 / 7, misaligned base, a source allocation with nothing behind the pointer:
+    # SHA-256's whole-chunk path once read 64 bytes at (and before) the pointer for an empty message (found by tests/soak_hash.py)
+    want = {"skein512": oracle.skein512(b"", 512), "skein": oracle.skein256(b"", 128), "sha256mb": hashlib.sha256(b"").digest()}
+    s = torch.cuda.current_stream().cuda_stream
+    for alg, w in want.items():
+        for stride, shift, count in ((0, 0, 263), (7, 1, 70), (16, 0, 5), (0, 3, 1)):
+            src = torch.zeros(stride * count + shift + 1, dtype=torch.uint8, device="cuda")
+            dig = torch.zeros(count * len(w), dtype=torch.uint8, device="cuda")
+            cw.dev_hash(alg, src.data_ptr() + shift, 0, count, dig.data_ptr(), s, src_stride=stride)
+            torch.cuda.synchronize()
+            got = dig.cpu().numpy().reshape(count, len(w))
+            assert all(got[i].tobytes() == w for i in range(count)), (alg, stride, shift)
 
 
 def test_slots_do_hashing(cw, oracle):
