@@ -28,6 +28,7 @@ their input blocks ("roundtrip"); a mismatch aborts the run instead of printing 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -40,6 +41,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0    # PCIe Gen5 x16, one direction (same guide)
 SEED = 0xC0FFEE
+# Rehearsal of the N > 1 path on a box with ONE GPU (tests/test_gpu_bench_world2.py): every rank uses cuda:0 and the gather runs over
+# gloo, because RCCL refuses two ranks on one device.  Everything else -- shards, kernels, double-buffered gather, fences, timing,
+# checks -- is the code an 8-GPU run executes.  The line is marked "rehearsal" and is never a benchmark number.
+REHEARSE = os.environ.get("CW_BENCH_REHEARSE") == "gloo-one-gpu"
 HASH_IDS = {"skein512": 0, "skein": 1, "sha256mb": 2}
 COMP_IDS = {"lz4": 0, "lzf": 1}
 
@@ -217,7 +222,7 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
                 h.wait()
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if REHEARSE else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(warmup):
@@ -374,6 +379,9 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
                      "alg_bytes_per_block": round(alg_bytes[dom], 1)},
         "kernels": dict(kernels, note="codec and hash run concurrently on two streams; durations overlap"),
         "parity_spot_check": spot,
+        # what the result gather delivered on rank 0 (all ranks' digests in block order): comparable between an N-rank run and a
+        # one-rank run over the same global block range
+        "gathered": {"digests": int(all_digests.shape[0]), "sha256": hashlib.sha256(all_digests.cpu().numpy().tobytes()).hexdigest()},
     }
     if roundtrip:
         leg["roundtrip"] = roundtrip
@@ -516,10 +524,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if REHEARSE:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        if REHEARSE:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
     cw.init(local_rank)
 
     bs, nb = args.block_bytes, args.blocks_per_gpu
@@ -543,7 +556,10 @@ def main():
         "roofline": head["roofline"],
         "kernels": head["kernels"],
         "parity_spot_check": head["parity_spot_check"],
+        "gathered": head["gathered"],
     }
+    if REHEARSE:
+        out["rehearsal"] = "CW_BENCH_REHEARSE=gloo-one-gpu: all ranks on cuda:0, gather over gloo -- a test of the N > 1 code path, not a benchmark number"
     if "roundtrip" in head:
         out["roundtrip"] = head["roundtrip"]
     if "standalone" in head:
