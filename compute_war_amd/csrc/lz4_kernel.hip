@@ -1391,7 +1391,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // owns a block and runs the serial parser as it stands (the oracle's loop, one probe per iteration), its table in global
 // memory (16 KiB per lane, zeroed by the lane when it takes a block): 64 chains per wavefront, tens of thousands per
 // chip, bound by how many random table / candidate accesses the memory system retires, not by any one chain's latency.
-// It only pays when there are that many blocks: lz4_launch uses it from kLaneMinBlocks queued blocks on.
+// It only pays when there are that many blocks: lz4_launch uses it from kLaneMidBlocks queued blocks on.
 //
 // Every lane is in one of the states below; an iteration of the wavefront's loop runs one step of every lane:
 //   PROBE   the parser's search loop body, or the re-test right after a match (same table traffic, different follow-up)
@@ -1400,7 +1400,9 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 //   NEXT    pull the next queued block, zero the table
 // Per iteration a lane's dependent memory chain is: its 16 bytes around ip -> table slot -> the candidate's 16 bytes.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kLaneMinBlocks = 24576; // below ~24 Ki queued 64 KiB blocks the chip is not full and the wavefront parser's 14-16 GB/s win
+// blocks > 4 KiB: below kLaneMidBlocks queued blocks the wavefront-per-block parser's 13-14 GB/s win; [mid, wide): lanes with two
+// positions per iteration (every lane holds one block: latency regime), from kLaneWideBlocks on one (random-line regime); lz4_launch
+constexpr uint32_t kLaneMidBlocks = 10240, kLaneWideBlocks = 49152;
 constexpr uint32_t kLaneMinSmall = 98304;  // LDS-staged blocks: lanes beside the LDS-resident parser from 96 Ki blocks on
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
@@ -1690,11 +1692,11 @@ template <int K>
 __global__ void __launch_bounds__(64)
 lz4_lanes_ring_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                       uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
-                      uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve)
+                      uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve, uint32_t max_blocks)
 {
     __shared__ uint32_t ring[(kRingBytes / 4) * 64]; // dword d of lane l's ring at [d * 64 + l]: a lane only touches its column
     const uint32_t qcount = counters[1];
-    if (qcount < min_blocks) return;
+    if (qcount < min_blocks || qcount >= max_blocks) return; // (the queue's length decides on the device which launch parses it)
     if ((size_t)blockIdx.x * 64 >= qcount) return; // (as in lz4_lanes_kernel)
     const uint32_t lane = threadIdx.x;
     uint32_t *tab = reinterpret_cast<uint32_t *>(tables) + ((size_t)blockIdx.x * 64 + lane) * (1u << 13); // fingerprint:16 | position:16
@@ -2087,7 +2089,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (use_fp) lds = kTabBytes + kFpBytes;
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
     // Large batches: the lane-per-block parser.  Two regimes:
-    //  * blocks read from global memory (> 4 KiB), from kLaneMinBlocks queued blocks on: the lanes take the whole queue, the
+    //  * blocks read from global memory (> 4 KiB), from kLaneMidBlocks queued blocks on: the lanes take the whole queue, the
     //    wavefront-per-block parser only what they leave (running it beside the lanes gains nothing there: both end up waiting
     //    for the same memory system -- 33.1 vs 34.2 GB/s);
     //  * LDS-staged blocks (<= 4 KiB), from kLaneMinSmall blocks on: the lanes run BESIDE the LDS-resident parser on a second
@@ -2097,12 +2099,22 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // CW_LZ4_LANES=0 switches it off, =N sets the threshold (1: every queued block, in the tests); CW_LANES_WPC = its
     // wavefronts per CU, CW_LANES_CONCURRENT=0|1 forces the regime, CW_LANES_RESERVE the blocks left to the wavefronts.
     static const char *lanes_env = getenv("CW_LZ4_LANES");
-    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : kLaneMinBlocks);
+    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : kLaneMidBlocks);
     bool lanes_used = false, lanes_beside = false;
     static const char *lf_env = getenv("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
     const bool lanes_fp = !(lf_env && lf_env[0] == '0');
-    static const char *lr_env = getenv("CW_LZ4_LANES_RING"); // 0 = input from global memory (lz4_lanes_kernel); 1, 2 = positions per iteration
-    const int lanes_ring = lr_env ? atoi(lr_env) : 1;
+    // CW_LZ4_LANES_RING: 0 = input from global memory (lz4_lanes_kernel); 1, 2, 4, 8 = the ring form with that many positions per
+    // iteration whatever the queue's length.  Unset: the ring form, K chosen ON THE DEVICE by the queue's length -- two launches,
+    // each of which returns at once unless the length lies in its range:
+    //   [kLaneMidBlocks, kLaneWideBlocks)  K = 2.  Every lane holds one block and the call lasts as long as one lane needs for
+    //       one block: latency, not lines, so the second position's table entry and candidate requested together with the
+    //       first's pay (text, 64 KiB, 16 Ki / 24 Ki / 32 Ki blocks: 21.1 / 26.0 / 29.9 GB/s against 16.4 / 21.0 / 27.0 with K = 1
+    //       and 14.2 for the wavefront parser, which keeps everything below ~10 Ki blocks: 8 Ki blocks 13.5 against 11.8);
+    //   [kLaneWideBlocks, ...)             K = 1.  Enough chains to be bound by the memory system's random lines, where the
+    //       lines of the speculative second position only cost (64 Ki blocks: 38.3 against 35.6 GB/s).
+    //   K = 4 / 8 are never better (16 Ki blocks: 20.0 / 16.4 GB/s): each position adds instructions to every iteration.
+    static const char *lr_env = getenv("CW_LZ4_LANES_RING");
+    const int lanes_ring = lr_env ? atoi(lr_env) : -1; // -1: by queue length
     if (!use_fp && lane_min && nblocks >= lane_min && n >= 64) {
         static const char *lw_env = getenv("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
@@ -2133,15 +2145,22 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             if ((e = hipStreamWaitEvent(wsp.side, wsp.fork, 0)) != hipSuccess) return e;
         }
         hipStream_t ls = lanes_beside ? wsp.side : stream;
+        const uint32_t no_max = 0xFFFFFFFFu;
+#define CW_RING(K, LO, HI) hipLaunchKernelGGL(lz4_lanes_ring_kernel<K>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, \
+                                              sizes, queue, counters, wsp.lane_tabs, LO, reserve, HI)
         if (n <= 4096)
             hipLaunchKernelGGL(lz4_lanes_kernel<kLaneTagged>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
                                counters, wsp.lane_tabs, lmin, reserve);
-        else if (lanes_ring == 1)
-            hipLaunchKernelGGL(lz4_lanes_ring_kernel<1>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
-                               counters, wsp.lane_tabs, lmin, reserve);
-        else if (lanes_ring == 2)
-            hipLaunchKernelGGL(lz4_lanes_ring_kernel<2>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
-                               counters, wsp.lane_tabs, lmin, reserve);
+        else if (lanes_ring < 0 && lanes_beside) CW_RING(1, lmin, no_max); // (a profiling regime: one launch beside the wavefront parser)
+        else if (lanes_ring < 0) {
+            if (lmin < kLaneWideBlocks) CW_RING(2, lmin, kLaneWideBlocks);
+            if (nblocks >= kLaneWideBlocks) CW_RING(1, lmin < kLaneWideBlocks ? kLaneWideBlocks : lmin, no_max);
+        }
+        else if (lanes_ring == 1) CW_RING(1, lmin, no_max);
+        else if (lanes_ring == 2) CW_RING(2, lmin, no_max);
+        else if (lanes_ring == 4) CW_RING(4, lmin, no_max);
+        else if (lanes_ring == 8) CW_RING(8, lmin, no_max);
+#undef CW_RING
         else if (lanes_fp)
             hipLaunchKernelGGL(lz4_lanes_kernel<kLaneFp>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
                                counters, wsp.lane_tabs, lmin, reserve);
@@ -2184,7 +2203,12 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     {
         static thread_local char names[192];
-        const char *lname = n <= 4096 ? "cw::lz4_lanes_kernel<1>" : lanes_ring == 1 ? "cw::lz4_lanes_ring_kernel<1>" : lanes_ring == 2 ? "cw::lz4_lanes_ring_kernel<2>"
+        const char *lname = n <= 4096 ? "cw::lz4_lanes_kernel<1>"
+                            : lanes_ring < 0 ? (lanes_beside ? "cw::lz4_lanes_ring_kernel<1>" : nblocks >= kLaneWideBlocks && lane_min < kLaneWideBlocks
+                                                ? "cw::lz4_lanes_ring_kernel<2> or <1> by queue length" : nblocks >= kLaneWideBlocks ? "cw::lz4_lanes_ring_kernel<1>"
+                                                : "cw::lz4_lanes_ring_kernel<2>")
+                            : lanes_ring == 1 ? "cw::lz4_lanes_ring_kernel<1>" : lanes_ring == 2 ? "cw::lz4_lanes_ring_kernel<2>"
+                            : lanes_ring == 4 ? "cw::lz4_lanes_ring_kernel<4>" : lanes_ring == 8 ? "cw::lz4_lanes_ring_kernel<8>"
                             : lanes_fp ? "cw::lz4_lanes_kernel<2>" : "cw::lz4_lanes_kernel<0>"; // (as rocprofv3 prints the instantiations)
         snprintf(names, sizeof names, "%s + %s%s%s", scan_name, lanes_used ? lname : "",
                  lanes_used ? (lanes_beside ? " beside " : " (large queues), then ") : "",

@@ -255,7 +255,8 @@ def test_lane_per_block_lz4_parser_is_exact():
     outs = []
     # blocks > 4 KiB: the ring form (input in an LDS ring, fingerprints in the table; CW_LZ4_LANES_RING=2: two positions per
     # iteration, =0: lz4_lanes_kernel with / without fingerprints, which blocks <= 4 KiB always use in its tagged form)
-    for env in ({}, {"CW_LZ4_LANES": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "2"},
+    for env in ({}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "1"}, {"CW_LZ4_LANES": "1", "CW_LANES_WPC": "1"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "2"},
+                {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "4"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "8"},
                 {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "0"}, {"CW_LZ4_LANES": "1", "CW_LZ4_LANES_RING": "0", "CW_LZ4_LANES_FP": "0"}):
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert r.returncode == 0, r.stderr[-2000:]
@@ -264,7 +265,8 @@ def test_lane_per_block_lz4_parser_is_exact():
     for rows in zip(*outs):
         assert all(r[:3] == rows[0][:3] for r in rows), rows
         assert "lanes" not in " ".join(rows[0]) and "lz4_lanes" in " ".join(rows[1])
-    assert "lz4_lanes_ring_kernel" in " ".join(outs[1][0]) and "lz4_lanes_kernel" in " ".join(outs[4][0])
+    assert "lz4_lanes_ring_kernel" in " ".join(outs[1][0]) and "lz4_lanes_kernel" in " ".join(outs[6][0])
+    assert "lz4_lanes_ring_kernel<4>" in " ".join(outs[4][0]) and "lz4_lanes_ring_kernel<8>" in " ".join(outs[5][0])
 
 
 def test_lane_per_block_lzf_parser_is_exact():
@@ -463,7 +465,8 @@ def test_lane_per_block_decoders():
 def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
     """At the sizes where the launch policy itself switches the lane parsers on -- 256 Ki and 64 Ki blocks of 4 KiB (lanes BESIDE the
     LDS-resident parsers, real interleavings of the shared queue / the top-down and bottom-up claims) and 32 Ki blocks of 64 KiB
-    (lanes take the queue) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
+    (lanes take the queue, two positions per iteration below 48 Ki queued blocks), 64 Ki blocks of 8 KiB (one position per iteration)
+    and 14 Ki blocks of 16 KiB (just above the LZ4 lanes' lower threshold, below LZF's) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
     (CW_LZ4_LANES=0 CW_LZF_LANES=0), which the parity tests pin to the oracle.  Compared through a Skein-512 digest per 64 KiB of
     the packed stream, computed on the device."""
     prog = (
@@ -474,7 +477,7 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         "s = torch.cuda.current_stream().cuda_stream\n"
         "data = b''.join(corpus_file(n) for n in corpus_names())\n"
         "rng = np.random.default_rng(11)\n"
-        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768)):\n"
+        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768), (8192, 65536), (16384, 14336)):\n"
         "    a = np.frombuffer((data * (nb * bs // len(data) + 1))[:nb * bs], dtype=np.uint8).copy()\n"
         "    for o in range(0, nb * bs - 65536, 7 * 65536): a[o:o + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)\n"
         "    src = torch.from_numpy(a).cuda(); del a\n"
@@ -500,10 +503,11 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
         assert r.returncode == 0, (env, r.stderr[-2000:])
         outs.append([ln.split(None, 5) for ln in r.stdout.splitlines() if ln.startswith("out ")])
-    assert len(outs[0]) == 6 and len(outs[1]) == 6
+    assert len(outs[0]) == 10 and len(outs[1]) == 10
     for i, (a, b) in enumerate(zip(*outs)):
         assert a[:5] == b[:5], (a, b)
         # 64 Ki blocks of 4 KiB: as many blocks as a full grid has lanes (every lane asks at once -- the case a check-then-add
         # protocol got wrong); below LZ4's threshold, above LZF's
-        assert ("lanes" in a[5]) == (i != 2) and "lanes" not in b[5], (a, b)
+        assert ("lanes" in a[5]) == (i not in (2, 9)) and "lanes" not in b[5], (a, b)
+    assert "ring_kernel<2> or <1>" in outs[0][6][5] and outs[0][8][5].count("ring_kernel<2>") == 1, (outs[0][6], outs[0][8])
     assert "beside" in outs[0][0][5] and "beside" in outs[0][1][5] and "beside" in outs[0][3][5]
