@@ -20,7 +20,7 @@
 //                spans, straight-line memory operations), lz4_scan_stream_kernel (other aligned sizes and span
 //                tails), lz4_scan_kernel (unaligned: gathers).
 //   2. parse  -- lz4_lanes_kernel: one block per LANE, the serial parser as it stands, tables in global memory -- tens of
-//                thousands of chains instead of the 2,560 that LDS admits.  Blocks > 4 KiB, from 24 Ki queued blocks on: it
+//                thousands of chains instead of the 2,560 that LDS admits.  Blocks > 4 KiB, from 10-14 Ki queued blocks on: it
 //                takes the whole queue.  Blocks <= 4 KiB, from 96 Ki blocks on: it runs BESIDE lz4_parse_kernel on a second
 //                stream, both pulling from the scan's queue (one is bound by LDS capacity and chain latency, the other by
 //                random memory lines: the rates add).
@@ -1402,7 +1402,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // ---------------------------------------------------------------------------------------------------
 // blocks > 4 KiB: below kLaneMidBlocks queued blocks the wavefront-per-block parser's 13-14 GB/s win; [mid, wide): lanes with two
 // positions per iteration (every lane holds one block: latency regime), from kLaneWideBlocks on one (random-line regime); lz4_launch
-constexpr uint32_t kLaneMidBlocks = 10240, kLaneWideBlocks = 49152;
+constexpr uint32_t kLaneMidBlocks = 10240, kLaneMidSmaller = 14336, kLaneWideBlocks = 49152;
 constexpr uint32_t kLaneMinSmall = 98304;  // LDS-staged blocks: lanes beside the LDS-resident parser from 96 Ki blocks on
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
@@ -2099,7 +2099,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // CW_LZ4_LANES=0 switches it off, =N sets the threshold (1: every queued block, in the tests); CW_LANES_WPC = its
     // wavefronts per CU, CW_LANES_CONCURRENT=0|1 forces the regime, CW_LANES_RESERVE the blocks left to the wavefronts.
     static const char *lanes_env = getenv("CW_LZ4_LANES");
-    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : kLaneMidBlocks);
+    // (a lane's time for a block and the wavefront parser's time for a batch both scale with the block size, so the break-even is a
+    // number of blocks: ~50 ms x 14 GB/s / 64 KiB at 64 KiB; the wavefront parser is faster on smaller blocks -- 19-21 GB/s -- hence 14 Ki)
+    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : kLaneMidSmaller);
     bool lanes_used = false, lanes_beside = false;
     static const char *lf_env = getenv("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
     const bool lanes_fp = !(lf_env && lf_env[0] == '0');

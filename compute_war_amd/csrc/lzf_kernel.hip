@@ -16,7 +16,7 @@
 //
 // Kernels (DESIGN.md 4.4 has the measurements):
 //   lzf_lanes_kernel   one block per LANE, liblzf's loop as it stands, 128 KiB table per lane in global memory.  Blocks
-//                      > 4 KiB, from 24 Ki blocks on: the whole batch.  Blocks <= 4 KiB, from 48 Ki blocks on: BESIDE the
+//                      > 4 KiB, from 12 Ki blocks on: the whole batch.  Blocks <= 4 KiB, from 48 Ki blocks on: BESIDE the
 //                      link/chain rounds on a second stream, the lanes pulling from the top of the batch while the rounds
 //                      climb from the bottom (LaneShare);
 //   lzf_links_kernel + lzf_chain_kernel   (everything else from 16 bytes on) per-position "previous position with my slot"
@@ -820,7 +820,10 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 // 65,536 x u16 table in global memory (128 KiB per lane, zeroed by the lane when it takes a block).  No links, no skip
 // flags, no lane-order assumption: the parse is the serial one.
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kLzfLaneMinBlocks = 24576;
+// A lane needs ~66 ms for a 64 KiB block of text however few lanes there are, the link/chain kernels run at 8.5 GB/s: the lanes win
+// from ~9 Ki compressible blocks on (text, 64 KiB, 12 Ki / 16 Ki / 20 Ki / 24 Ki blocks: 13.2 / 16.3 / 13.6 / 15.2 GB/s against 8.5; the dip
+// is the second wavefront on some CUs' SIMDs).  A batch that is a third noise or more goes back to the chain kernels anyway.
+constexpr uint32_t kLzfLaneMinBlocks = 12288;
 constexpr uint32_t kLzfLaneMinSmall = 49152;  // blocks <= 4 KiB: lanes beside the rounds from 48 Ki blocks on (64 Ki: 19.1 vs 13.8 GB/s)
 constexpr size_t kLzfBesideRound = 16384;     // ... in rounds of 16 Ki blocks, the last 16 Ki unclaimed blocks left to the rounds.  4 KiB blocks, text /
                                               // 50 % noise / noise, GB/s -- 1 Mi blocks: rounds of 8 Ki 29.8 / 24.7 / 52.9, 16 Ki 33.1 / 29.0 / 57.7,
