@@ -21,7 +21,7 @@
 //                tails), lz4_scan_kernel (unaligned: gathers).
 //   2. parse  -- lz4_lanes_kernel: one block per LANE, the serial parser as it stands, tables in global memory -- tens of
 //                thousands of chains instead of the 2,560 that LDS admits.  Blocks > 4 KiB, from 10-14 Ki queued blocks on: it
-//                takes the whole queue.  Blocks <= 4 KiB, from 96 Ki blocks on: it runs BESIDE lz4_parse_kernel on a second
+//                takes the whole queue.  Blocks <= 4 KiB, from 60 Ki blocks on: it runs BESIDE lz4_parse_kernel on a second
 //                stream, both pulling from the scan's queue (one is bound by LDS capacity and chain latency, the other by
 //                random memory lines: the rates add).
 //                lz4_parse_kernel (everything else, and what the lanes leave): full parse of the queued blocks, one block per
@@ -1403,7 +1403,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // blocks > 4 KiB: below kLaneMidBlocks queued blocks the wavefront-per-block parser's 13-14 GB/s win; [mid, wide): lanes with two
 // positions per iteration (every lane holds one block: latency regime), from kLaneWideBlocks on one (random-line regime); lz4_launch
 constexpr uint32_t kLaneMidBlocks = 10240, kLaneMidSmaller = 14336, kLaneWideBlocks = 49152;
-constexpr uint32_t kLaneMinSmall = 98304;  // LDS-staged blocks: lanes beside the LDS-resident parser from 96 Ki blocks on
+constexpr uint32_t kLaneMinSmall = 61440;  // LDS-staged blocks: lanes beside the LDS-resident parser from 60 Ki blocks on (64 Ki blocks of text: 28.5 against 25.7 GB/s)
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
 __device__ __forceinline__ void lane_put_len(uint8_t *__restrict__ out, uint32_t &op, uint32_t extra)
@@ -2120,8 +2120,13 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (!use_fp && lane_min && nblocks >= lane_min && n >= 64) {
         static const char *lw_env = getenv("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
-        size_t lgrid = (nblocks + 63) / 64;
-        if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
+        size_t lgrid = (nblocks + 63) / 64, lcap = 256 * lwpc;
+        // LDS-staged blocks, lanes beside the wavefront parser: lanes for about half of the blocks (2 .. 8 wavefronts per CU).  With
+        // fewer lanes each is faster (less traffic per probe in flight), and a batch of 64 Ki .. 256 Ki blocks is over before a lane
+        // has parsed more than two or three (text, 4 KiB, 80 Ki / 128 Ki / 256 Ki blocks: 2 wavefronts per CU 34.4 / 33.6 / 35.6 GB/s,
+        // 4: 27.7 / 39.6 / 36.5, 8: 24.9 / 26.0 / 39.0-41.0; the wavefront parser alone 25.8)
+        if (staged && !(lw_env && atoi(lw_env) > 0)) lcap = nblocks / 128 < 512 ? 512 : nblocks / 128 > 2048 ? 2048 : nblocks / 128;
+        if (lgrid > lcap) lgrid = lcap;
         if (wsp.lane_cap < lgrid * 64) {
             if (wsp.lane_tabs) { e = hipFree(wsp.lane_tabs); if (e != hipSuccess) return e; }
             wsp.lane_tabs = nullptr; wsp.lane_cap = 0;
@@ -2140,8 +2145,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 if ((e = hipEventCreateWithFlags(&wsp.fork, hipEventDisableTiming)) != hipSuccess) return e;
                 if ((e = hipEventCreateWithFlags(&wsp.join, hipEventDisableTiming)) != hipSuccess) return e;
             }
-            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 8192u : 24576u); // measured 4 KiB text, 1 Mi blocks: 8 Ki..32 Ki 42.8 GB/s, 48 Ki 39.8
-            if (lane_min > 1 && lmin < 3 * reserve) lmin = 3 * reserve; // (CW_LZ4_LANES=1 in the tests: no reserve)
+            // what the wavefront parser gets through while a lane parses its last block: 4 KiB text, 1 Mi blocks: 8 Ki..40 Ki 40-43 GB/s, 48 Ki 39.8;
+            // 256 Ki blocks: 16 Ki / 28 Ki / 40 Ki 37.4 / 39.0 / 41.0
+            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 32768u : 24576u);
+            if (lane_min > 1 && lmin < reserve + reserve / 4) lmin = reserve + reserve / 4; // (CW_LZ4_LANES=1 in the tests: no reserve)
             if (lane_min == 1) reserve = 0;
             if ((e = hipEventRecord(wsp.fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(wsp.side, wsp.fork, 0)) != hipSuccess) return e;
