@@ -16,7 +16,7 @@ for leg in "${LEGS[@]}"; do
   rocprofv3 --kernel-trace --stats -d $O/prof_$1 -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --hash $2 --comp $3 --block-bytes $4 --data $5 --blocks-per-gpu $(( (4<<30) / $4 )) --steps 3 --warmup 1 > $O/prof_$1.json 2> $O/prof_$1.err
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_headline_$c -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --steps 1 --warmup 0 > $O/pmc_headline_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_headline_$c -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --no-roundtrip --steps 1 --warmup 0 > $O/pmc_headline_$c.log 2>&1
   for leg in "${LEGS[@]}"; do
     set -- $leg
     rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$1_$c -o p -f csv -- python3 bench.py --no-legs --no-cpu-baseline --hash $2 --comp $3 --block-bytes $4 --data $5 --blocks-per-gpu $(( (4<<30) / $4 )) --steps 1 --warmup 0 > $O/pmc_$1_$c.log 2>&1
