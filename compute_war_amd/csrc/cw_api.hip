@@ -743,6 +743,14 @@ int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack)
     return CW_OK;
 }
 
+// Chunks of compressible blocks > 4 KiB grow once the first results are in.  A 512 MiB chunk is 8,192 blocks of 64 KiB: the regime of the
+// wavefront-per-block parsers (13 GB/s LZ4, 8.5 GB/s LZF on text), and the codec, not the link, bounds the call.  2 GiB are 32 Ki blocks,
+// which the lane parsers take (the number of blocks in a call): 8 GiB of the corpus in page-locked memory, Skein-512 + LZ4
+// 23.0 -> 31.0 GB/s, SHA-256 + LZF 11.4 -> 24.5.  Noise stays with 512 MiB (45.7 GB/s; 40.5 with 2 GiB chunks: fill and drain).  Only
+// with the caller's buffers page-locked (no 2 GiB of staging per slot) and CW_HOST_CHUNK_MB unset; 18.5 GiB of device memory per calling
+// thread once grown.
+constexpr size_t kBigChunkBytes = (size_t)2 << 30;
+
 int host_pipeline(HostJob &j)
 {
     ThreadCtx *cp;
@@ -751,17 +759,40 @@ int host_pipeline(HostJob &j)
     ThreadCtx &c = *cp;
     if (j.nblocks == 0 || (!j.do_hash && !j.do_comp)) { if (j.offsets) j.offsets[0] = 0; return CW_OK; }
     const size_t chunk = pipeline_chunk(j.bb, j.nblocks);
-    const size_t nchunks = (j.nblocks + chunk - 1) / chunk;
     j.src_pinned = is_pinned(j.src);
     j.packed_pinned = j.packed && is_pinned(j.packed);
     j.packed_off = 0;
-    for (size_t k = 0; k < nchunks + 2 && rc == CW_OK; k++) {
-        if (k < nchunks) {
-            const size_t first = k * chunk;
-            rc = pipe_issue(c, j, c.slot[k % kSlots], first, j.nblocks - first < chunk ? j.nblocks - first : chunk);
+    static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
+    static const char *bk_env = getenv("CW_HOST_BIG_CHUNK_MB"); // test knob: the grown chunk's size (and growth although CW_HOST_CHUNK_MB is set)
+    const bool bk_set = bk_env && atol(bk_env) > 0;
+    const size_t big = (bk_set ? (size_t)atol(bk_env) << 20 : kBigChunkBytes) / (j.bb ? j.bb : 1);
+    const bool may_grow = (bk_set || !(ck_env && atol(ck_env) > 0)) && j.do_comp && j.bb > 4096 && j.src_pinned && j.packed_pinned && big > chunk;
+    size_t next = 0, issued = 0, seen_in = 0, seen_out = 0; // blocks handed out; chunks issued; bytes in / out of the chunks reaped so far
+    for (size_t k = 0; rc == CW_OK && (next < j.nblocks || k < issued + 2); k++) {
+        if (next < j.nblocks) {
+            const size_t left = j.nblocks - next;
+            size_t n = left < chunk ? left : chunk;
+            if (may_grow && seen_in && seen_in / 10 * 9 >= seen_out && left > chunk) // compressible so far (>= 10 % saved)
+                n = left >= 2 * big ? big : left > big ? (left + 1) / 2 : left;
+            static const char *dbg_env = getenv("CW_DEBUG_HOST"); // prints the chunks of a call (tests)
+            if (dbg_env && dbg_env[0] == '1') fprintf(stderr, "cw host pipeline: chunk %zu = %zu blocks of %zu B\n", issued, n, j.bb);
+            rc = pipe_issue(c, j, c.slot[k % kSlots], next, n);
+            next += n;
+            issued++;
         }
-        if (rc == CW_OK && k >= 1 && k - 1 < nchunks) rc = pipe_reap(c, j, c.slot[(k - 1) % kSlots]);
-        if (rc == CW_OK && k >= 2) rc = pipe_finish(j, c.slot[(k - 2) % kSlots]);
+        if (rc == CW_OK && k >= 1 && k - 1 < issued) {
+            Slot &s = c.slot[(k - 1) % kSlots];
+            rc = pipe_reap(c, j, s);
+            seen_in += s.n * j.bb;
+            seen_out += s.total;
+            if (may_grow) { // a block that did not fit (LZF: size 0) is kept raw by the caller: it counts as not compressed
+                const uint32_t *sz = (const uint32_t *)s.h_meta.p;
+                size_t raw = 0;
+                for (size_t i = 0; i < s.n; i++) raw += sz[i] == 0;
+                seen_out += raw * j.bb;
+            }
+        }
+        if (rc == CW_OK && k >= 2 && k - 2 < issued) rc = pipe_finish(j, c.slot[(k - 2) % kSlots]);
     }
     if (rc != CW_OK) { pipe_drain(c); return rc; }
     if (j.offsets) j.offsets[j.nblocks] = j.packed_off;

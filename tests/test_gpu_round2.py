@@ -86,6 +86,48 @@ def test_host_pipeline_many_small_chunks_subprocess(oracle):
         assert line.split()[-1] == h.hexdigest(), (comp, bs)
 
 
+def test_host_pipeline_growing_chunks_subprocess(oracle):
+    """Chunks of compressible blocks > 4 KiB grow once the first results are in (page-locked buffers only).  With CW_HOST_CHUNK_MB=1 and
+    CW_HOST_BIG_CHUNK_MB=3 a 17 MiB batch of corpus text goes 1, 1, 3, 3, 3, 3, 3 MiB; one that starts with 4 MiB of noise keeps 1 MiB
+    chunks until the text arrives (LZF: its raw-stored blocks count as not compressed).  Results against the oracle."""
+    prog = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import numpy as np, hashlib, compute_war_amd as cw\n"
+        "from conftest import corpus_file\n"
+        "cw.init(0)\n"
+        "text = (corpus_file('lcet10.txt') + corpus_file('kennedy.xls') + corpus_file('ptt5')) * 12\n"
+        "noise = np.random.default_rng(3).integers(0, 256, 4 << 20, dtype=np.uint8).tobytes()\n"
+        "for name, data in (('text', text[:17 << 20]), ('noise_then_text', noise + text[:9 << 20]), ('odd_tail', text[:(7 << 20) + 65536 * 5])):\n"
+        "    for comp, bs in (('lz4', 65536), ('lzf', 16384)):\n"
+        "        d, sizes, offsets, packed = cw.hash_and_compress_packed('skein512', comp, data, bs, pinned=True)\n"
+        "        print(name, comp, bs, hashlib.sha256(d.tobytes() + sizes.tobytes() + packed.tobytes()).hexdigest())\n" % (ROOT, ROOT))
+    outs = []
+    for env in ({"CW_HOST_CHUNK_MB": "1", "CW_HOST_BIG_CHUNK_MB": "3", "CW_DEBUG_HOST": "1"}, {"CW_HOST_CHUNK_MB": "1"}, {}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(r.stdout.strip().splitlines())
+        if "CW_DEBUG_HOST" in env:
+            chunks = [int(ln.split("=")[1].split()[0]) for ln in r.stderr.splitlines() if ln.startswith("cw host pipeline: chunk")]
+            # first call: 17 MiB of text at 64 KiB: 16, 16, then 48-block chunks (the last two halve what is left)
+            assert chunks[:4] == [16, 16, 48, 48] and sum(chunks[:7]) == 272, chunks[:12]
+            assert 192 in chunks   # LZF at 16 KiB: 3 MiB chunks too
+            # noise first: the 1 MiB chunks stay while what has been seen does not compress (a run of small chunks that text alone never shows)
+            assert "16,16,16,16,16" in ",".join(map(str, chunks)), chunks
+    assert len(outs[0]) == 6 and outs[0] == outs[1] == outs[2], outs
+    import hashlib
+    from conftest import corpus_file
+    text = (corpus_file("lcet10.txt") + corpus_file("kennedy.xls") + corpus_file("ptt5")) * 12
+    data = text[: (7 << 20) + 65536 * 5]   # the smallest case against the oracle itself
+    for line, (comp, bs) in zip(outs[0][4:], (("lz4", 65536), ("lzf", 16384))):
+        cfn = oracle.lz4_compress if comp == "lz4" else oracle.lzf_compress
+        blocks = [data[i * bs:(i + 1) * bs] for i in range(len(data) // bs)]
+        cs = [cfn(b) for b in blocks]
+        h = hashlib.sha256(b"".join(oracle.skein512(b, 512) for b in blocks))
+        h.update(np.array([len(o) for o in cs], dtype=np.uint32).tobytes())
+        h.update(b"".join(cs))
+        assert line.split()[-1] == h.hexdigest(), (comp, bs)
+
+
 def test_gen_mixed_matches_host_twin_and_compresses(cw, oracle):
     import torch
     s = torch.cuda.current_stream().cuda_stream
