@@ -751,6 +751,17 @@ int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack)
 // thread once grown.
 constexpr size_t kBigChunkBytes = (size_t)2 << 30;
 
+// blocks of a grown chunk, or 0 when chunks of this job never grow
+size_t grown_chunk(const HostJob &j, size_t chunk, bool pinned_io)
+{
+    static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
+    static const char *bk_env = getenv("CW_HOST_BIG_CHUNK_MB"); // test knob: the grown chunk's size (and growth although CW_HOST_CHUNK_MB is set)
+    const bool bk_set = bk_env && atol(bk_env) > 0;
+    const size_t big = (bk_set ? (size_t)atol(bk_env) << 20 : kBigChunkBytes) / (j.bb ? j.bb : 1);
+    const bool may = (bk_set || !(ck_env && atol(ck_env) > 0)) && j.do_comp && j.bb > 4096 && pinned_io && big > chunk;
+    return may ? big : 0;
+}
+
 int host_pipeline(HostJob &j)
 {
     ThreadCtx *cp;
@@ -762,11 +773,8 @@ int host_pipeline(HostJob &j)
     j.src_pinned = is_pinned(j.src);
     j.packed_pinned = j.packed && is_pinned(j.packed);
     j.packed_off = 0;
-    static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
-    static const char *bk_env = getenv("CW_HOST_BIG_CHUNK_MB"); // test knob: the grown chunk's size (and growth although CW_HOST_CHUNK_MB is set)
-    const bool bk_set = bk_env && atol(bk_env) > 0;
-    const size_t big = (bk_set ? (size_t)atol(bk_env) << 20 : kBigChunkBytes) / (j.bb ? j.bb : 1);
-    const bool may_grow = (bk_set || !(ck_env && atol(ck_env) > 0)) && j.do_comp && j.bb > 4096 && j.src_pinned && j.packed_pinned && big > chunk;
+    const size_t big = grown_chunk(j, chunk, j.src_pinned && j.packed_pinned);
+    const bool may_grow = big != 0;
     size_t next = 0, issued = 0, seen_in = 0, seen_out = 0; // blocks handed out; chunks issued; bytes in / out of the chunks reaped so far
     for (size_t k = 0; rc == CW_OK && (next < j.nblocks || k < issued + 2); k++) {
         if (next < j.nblocks) {
@@ -853,7 +861,11 @@ int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, i
     HostJob j;
     int dummy = 0;
     if ((rc = host_job_init(j, hash_alg, comp_alg, &dummy, block_bytes, nblocks, &dummy, true)) != CW_OK) return rc;
-    const size_t chunk = pipeline_chunk(block_bytes, nblocks);
+    size_t chunk = pipeline_chunk(block_bytes, nblocks);
+    // a batch whose chunks may grow (host_pipeline): buffers, workspaces and lane tables for the grown chunk, so that the growth costs
+    // no allocation inside a timed window (18.5 GiB of device memory per calling thread)
+    const size_t big = grown_chunk(j, chunk, pinned_io != 0);
+    if (big && nblocks > 2 * chunk) chunk = nblocks - 2 * chunk < big ? nblocks - 2 * chunk : big;
     for (Slot &s : c->slot)
         if ((rc = slot_reserve(j, s, chunk, !pinned_io, !pinned_io)) != CW_OK) return rc;
     // One chunk's kernels on every slot (over whatever its device buffers hold): the codecs' per-stream workspaces -- queues, link
