@@ -1402,7 +1402,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // ---------------------------------------------------------------------------------------------------
 // blocks > 4 KiB: below kLaneMidBlocks queued blocks the wavefront-per-block parser's 13-14 GB/s win; [mid, wide): lanes with two
 // positions per iteration (every lane holds one block: latency regime), from kLaneWideBlocks on one (random-line regime); lz4_launch
-constexpr uint32_t kLaneMidBlocks = 10240, kLaneMidSmaller = 14336, kLaneWideBlocks = 49152;
+constexpr uint32_t kLaneMidBlocks = 10240, kLaneWideBlocks = 49152; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
 constexpr uint32_t kLaneMinSmall = 61440;  // LDS-staged blocks: lanes beside the LDS-resident parser from 60 Ki blocks on (64 Ki blocks of text: 28.5 against 25.7 GB/s)
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
@@ -2099,9 +2099,11 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // CW_LZ4_LANES=0 switches it off, =N sets the threshold (1: every queued block, in the tests); CW_LANES_WPC = its
     // wavefronts per CU, CW_LANES_CONCURRENT=0|1 forces the regime, CW_LANES_RESERVE the blocks left to the wavefronts.
     static const char *lanes_env = getenv("CW_LZ4_LANES");
-    // (a lane's time for a block and the wavefront parser's time for a batch both scale with the block size, so the break-even is a
-    // number of blocks: ~50 ms x 14 GB/s / 64 KiB at 64 KiB; the wavefront parser is faster on smaller blocks -- 19-21 GB/s -- hence 14 Ki)
-    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env) : (staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : kLaneMidSmaller);
+    // measured break-even with the wavefront parser on text (GB/s, wavefront parser / lanes): 64 KiB 16 Ki blocks 14.2 / 20.9; 16 KiB 16 Ki
+    // blocks 18.3 / 17.4, 24 Ki 18.3 / 20.7; 8 KiB 24 Ki blocks 20.9 / 18.5, 32 Ki 20.4 / 22.7 (a lane's fixed cost per block -- zeroing its
+    // 32 KiB table -- weighs more the smaller the block)
+    const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env)
+                              : staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : n > 16384 ? 14336u : n > 8192 ? 20480u : 28672u;
     bool lanes_used = false, lanes_beside = false;
     static const char *lf_env = getenv("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
     const bool lanes_fp = !(lf_env && lf_env[0] == '0');

@@ -1086,7 +1086,8 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const size_t ws_bytes = big ? (size_t)1 << 30 : (size_t)256 << 20; // links per round
         static const char *round_env = getenv("CW_LZF_ROUND"); // test knob: blocks per round (many rounds on small data)
         static const char *lanes_env = getenv("CW_LZF_LANES");
-        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? kLzfLaneMinBlocks : kLzfLaneMinSmall);
+        // (blocks of 4-8 KiB: the chain kernels win up to ~18 Ki blocks -- text, 8 KiB, 16 Ki blocks 11.0 against 10.6 GB/s, 24 Ki 11.3 / 13.0)
+        const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? (n > 8192 ? kLzfLaneMinBlocks : 18432u) : kLzfLaneMinSmall);
         static const char *cc_env = getenv("CW_LANES_CONCURRENT");
         const bool use_lanes = lane_min && nblocks >= lane_min;
         const bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);

@@ -508,7 +508,7 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
     """At the sizes where the launch policy itself switches the lane parsers on -- 256 Ki and 64 Ki blocks of 4 KiB (lanes BESIDE the
     LDS-resident parsers, real interleavings of the shared queue / the top-down and bottom-up claims) and 32 Ki blocks of 64 KiB
     (lanes take the queue, two positions per iteration below 48 Ki queued blocks), 64 Ki blocks of 8 KiB (one position per iteration)
-    and 16 Ki blocks of 16 KiB (14 Ki queued: just above both lower thresholds) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
+    and 24 Ki blocks of 16 KiB (21 Ki queued: just above the LZ4 lanes' lower threshold for that size) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
     (CW_LZ4_LANES=0 CW_LZF_LANES=0), which the parity tests pin to the oracle.  Compared through a Skein-512 digest per 64 KiB of
     the packed stream, computed on the device."""
     prog = (
@@ -519,7 +519,7 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         "s = torch.cuda.current_stream().cuda_stream\n"
         "data = b''.join(corpus_file(n) for n in corpus_names())\n"
         "rng = np.random.default_rng(11)\n"
-        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768), (8192, 65536), (16384, 16384)):\n"
+        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768), (8192, 65536), (16384, 24576)):\n"
         "    a = np.frombuffer((data * (nb * bs // len(data) + 1))[:nb * bs], dtype=np.uint8).copy()\n"
         "    for o in range(0, nb * bs - 65536, 7 * 65536): a[o:o + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)\n"
         "    src = torch.from_numpy(a).cuda(); del a\n"
