@@ -2100,8 +2100,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // wavefronts per CU, CW_LANES_CONCURRENT=0|1 forces the regime, CW_LANES_RESERVE the blocks left to the wavefronts.
     static const char *lanes_env = getenv("CW_LZ4_LANES");
     // measured break-even with the wavefront parser on text (GB/s, wavefront parser / lanes): 64 KiB 16 Ki blocks 14.2 / 20.9; 16 KiB 16 Ki
-    // blocks 18.3 / 17.4, 24 Ki 18.3 / 20.7; 8 KiB 24 Ki blocks 20.9 / 18.5, 32 Ki 20.4 / 22.7 (a lane's fixed cost per block -- zeroing its
-    // 32 KiB table -- weighs more the smaller the block)
+    // blocks 18.3 / 17.4, 24 Ki 18.3 / 20.7; 8 KiB 24 Ki blocks 20.9 / 18.5, 32 Ki 20.4 / 22.7 (on small blocks the wavefront parser
+    // is faster and a lane slower per byte: every block starts on an empty table, and has one to zero)
     const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env)
                               : staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : n > 16384 ? 14336u : n > 8192 ? 20480u : 28672u;
     bool lanes_used = false, lanes_beside = false;
