@@ -16,7 +16,7 @@
 //
 // Kernels (DESIGN.md 4.4 has the measurements):
 //   lzf_lanes_kernel   one block per LANE, liblzf's loop as it stands, 128 KiB table per lane in global memory.  Blocks
-//                      > 4 KiB, from 12 Ki blocks on: the whole batch.  Blocks <= 4 KiB, from 48 Ki blocks on: BESIDE the
+//                      > 4 KiB, from 12 Ki blocks on: the whole batch.  Blocks <= 4 KiB, from 28 Ki blocks on: BESIDE the
 //                      link/chain rounds on a second stream, the lanes pulling from the top of the batch while the rounds
 //                      climb from the bottom (LaneShare);
 //   lzf_links_kernel + lzf_chain_kernel   (everything else from 16 bytes on) per-position "previous position with my slot"
@@ -824,11 +824,11 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 // from ~9 Ki compressible blocks on (text, 64 KiB, 12 Ki / 16 Ki / 20 Ki / 24 Ki blocks: 13.2 / 16.3 / 13.6 / 15.2 GB/s against 8.5; the dip
 // is the second wavefront on some CUs' SIMDs).  A batch that is a third noise or more goes back to the chain kernels anyway.
 constexpr uint32_t kLzfLaneMinBlocks = 12288;
-constexpr uint32_t kLzfLaneMinSmall = 49152;  // blocks <= 4 KiB: lanes beside the rounds from 48 Ki blocks on (64 Ki: 19.1 vs 13.8 GB/s)
+constexpr uint32_t kLzfLaneMinSmall = 28672;  // blocks <= 4 KiB: lanes beside the rounds from 28 Ki blocks on (text, 32 Ki / 40 Ki / 64 Ki blocks: 16.1 / 19.5 / 21 against 13.5 GB/s)
 constexpr size_t kLzfBesideRound = 16384;     // ... in rounds of 16 Ki blocks, the last 16 Ki unclaimed blocks left to the rounds.  4 KiB blocks, text /
                                               // 50 % noise / noise, GB/s -- 1 Mi blocks: rounds of 8 Ki 29.8 / 24.7 / 52.9, 16 Ki 33.1 / 29.0 / 57.7,
                                               // 32 Ki 32.6 / 30.9 / 59.2; 96 Ki blocks: 25.6 / 36.3 / 50.5, 26.2 / 39.3 / 53.6, 23.1 / 36.4 / 55.0
-constexpr uint32_t kLzfBesideReserve = 16384;
+constexpr uint32_t kLzfBesideReserve = 16384, kLzfBesideReserveFew = 8192; // blocks left to the rounds; below 48 Ki blocks (32 Ki blocks: 16.1 against 13.2 GB/s with 16 Ki)
 
 // 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
 __device__ __forceinline__ uint32_t lzf_rd(const uint8_t *g, uint32_t ip, uint32_t n)
@@ -1127,7 +1127,9 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 4;
             size_t lgrid = (nblocks + 63) / 64;
             if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
-            if (beside && lgrid * 64 + kLzfBesideReserve > nblocks) lgrid = nblocks > kLzfBesideReserve + 64 ? (nblocks - kLzfBesideReserve) / 64 : 1; // (no lane without a block)
+            static const char *rs0_env = getenv("CW_LANES_RESERVE");
+            const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
+            if (beside && lgrid * 64 + want_reserve > nblocks) lgrid = nblocks > want_reserve + 64 ? (nblocks - want_reserve) / 64 : 1; // (no lane without a block)
             LinkSpace &w = entry->s;
             if (w.lane_cap < lgrid * 64) {
                 if (w.lane_tabs) { e = hipFree(w.lane_tabs); if (e != hipSuccess) return e; }
@@ -1152,7 +1154,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                     if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
                 }
                 static const char *rs_env = getenv("CW_LANES_RESERVE");
-                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : kLzfBesideReserve;
+                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
                 if (lane_reserve < 1) lane_reserve = 1; // (0 means "on their own" to the kernel; the protocol itself needs no reserve)
                 if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;

@@ -508,7 +508,8 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
     """At the sizes where the launch policy itself switches the lane parsers on -- 256 Ki and 64 Ki blocks of 4 KiB (lanes BESIDE the
     LDS-resident parsers, real interleavings of the shared queue / the top-down and bottom-up claims) and 32 Ki blocks of 64 KiB
     (lanes take the queue, two positions per iteration below 48 Ki queued blocks), 64 Ki blocks of 8 KiB (one position per iteration)
-    and 24 Ki blocks of 16 KiB (21 Ki queued: just above the LZ4 lanes' lower threshold for that size) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
+    24 Ki blocks of 16 KiB (21 Ki queued: just above the LZ4 lanes' lower threshold for that size) and 32 Ki blocks of 4 KiB (LZF lanes
+    beside the rounds with the small reserve) -- the packed output stream and the sizes are identical to those of the wavefront parsers alone
     (CW_LZ4_LANES=0 CW_LZF_LANES=0), which the parity tests pin to the oracle.  Compared through a Skein-512 digest per 64 KiB of
     the packed stream, computed on the device."""
     prog = (
@@ -519,7 +520,7 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         "s = torch.cuda.current_stream().cuda_stream\n"
         "data = b''.join(corpus_file(n) for n in corpus_names())\n"
         "rng = np.random.default_rng(11)\n"
-        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768), (8192, 65536), (16384, 24576)):\n"
+        "for bs, nb in ((4096, 262144), (4096, 65536), (65536, 32768), (8192, 65536), (16384, 24576), (4096, 32768)):\n"
         "    a = np.frombuffer((data * (nb * bs // len(data) + 1))[:nb * bs], dtype=np.uint8).copy()\n"
         "    for o in range(0, nb * bs - 65536, 7 * 65536): a[o:o + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)\n"
         "    src = torch.from_numpy(a).cuda(); del a\n"
@@ -545,11 +546,11 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
         assert r.returncode == 0, (env, r.stderr[-2000:])
         outs.append([ln.split(None, 5) for ln in r.stdout.splitlines() if ln.startswith("out ")])
-    assert len(outs[0]) == 10 and len(outs[1]) == 10
+    assert len(outs[0]) == 12 and len(outs[1]) == 12
     for i, (a, b) in enumerate(zip(*outs)):
         assert a[:5] == b[:5], (a, b)
         # 64 Ki blocks of 4 KiB: as many blocks as a full grid of LZF lanes (every lane asks at once -- the case a check-then-add
         # protocol got wrong); 56 Ki of them queued for LZ4: just below its lanes' threshold, so the launched lane kernel returns at once
-        assert "lanes" in a[5] and "lanes" not in b[5], (a, b)
+        assert ("lanes" in a[5]) == (i != 10) and "lanes" not in b[5], (a, b)   # (32 Ki blocks of 4 KiB: LZF lanes beside the rounds, no LZ4 lanes yet)
     assert "ring_kernel<2> or <1>" in outs[0][6][5] and outs[0][8][5].count("ring_kernel<2>") == 1, (outs[0][6], outs[0][8])
     assert "beside" in outs[0][0][5] and "beside" in outs[0][1][5] and "beside" in outs[0][3][5]
