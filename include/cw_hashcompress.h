@@ -120,8 +120,10 @@ int cw_hash_and_compress_packed(int hash_alg, int comp_alg, const void *src, siz
                                 uint64_t *offsets, uint32_t *sizes);
 /* Both forms run as a three-stage pipeline (host->device copy of chunk k+1 | kernels of chunk k | device->host copy of
  * chunk k-1: what HashOffload::Start()/Complete() were meant to be, HashOffload.h:26-40).  The copy engines read and
- * write page-locked host memory in place; other buffers go through pinned staging with one memcpy.  To get buffers
- * the engines can use directly:                                                                                    */
+ * write page-locked host memory in place; other buffers go through pinned staging with one memcpy.  Chunks are 512 MiB
+ * (4.6 GiB of device memory per calling thread and device); with page-locked buffers on both sides, chunks of blocks
+ * above 4 KiB grow to 2 GiB once the first results show that the data compresses (18.5 GiB then), because the codecs
+ * reach their rate only on tens of thousands of blocks at a time.  To get buffers the engines can use directly:       */
 /* initializeGpu() (:95-98) for the calling thread: its context on its device plus everything the batch path would allocate
  * on first use for batches of up to nblocks blocks (pinned_io: the caller's buffers are page-locked, no staging needed) */
 int   cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, int pinned_io);
