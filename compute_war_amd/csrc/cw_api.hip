@@ -762,6 +762,17 @@ size_t grown_chunk(const HostJob &j, size_t chunk, bool pinned_io)
     return may ? big : 0;
 }
 
+// grown chunks need 3 x (input + slots + packed stream) of device memory per calling thread: only when the device has it to spare
+// (many host threads on one device each run a pipeline of their own)
+bool room_to_grow(const ThreadCtx &c, const HostJob &j, size_t big)
+{
+    if (c.slot[0].src.cap >= big * j.bb && c.slot[kSlots - 1].src.cap >= big * j.bb) return true; // grown before
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t need = kSlots * big * (j.bb + 2 * j.d_stride + 64);
+    return free_b > need + ((size_t)16 << 30);
+}
+
 int host_pipeline(HostJob &j)
 {
     ThreadCtx *cp;
@@ -774,7 +785,7 @@ int host_pipeline(HostJob &j)
     j.packed_pinned = j.packed && is_pinned(j.packed);
     j.packed_off = 0;
     const size_t big = grown_chunk(j, chunk, j.src_pinned && j.packed_pinned);
-    const bool may_grow = big != 0;
+    const bool may_grow = big != 0 && j.nblocks > 2 * chunk && room_to_grow(c, j, big);
     size_t next = 0, issued = 0, seen_in = 0, seen_out = 0; // blocks handed out; chunks issued; bytes in / out of the chunks reaped so far
     for (size_t k = 0; rc == CW_OK && (next < j.nblocks || k < issued + 2); k++) {
         if (next < j.nblocks) {
@@ -865,7 +876,7 @@ int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, i
     // a batch whose chunks may grow (host_pipeline): buffers, workspaces and lane tables for the grown chunk, so that the growth costs
     // no allocation inside a timed window (18.5 GiB of device memory per calling thread)
     const size_t big = grown_chunk(j, chunk, pinned_io != 0);
-    if (big && nblocks > 2 * chunk) chunk = nblocks - 2 * chunk < big ? nblocks - 2 * chunk : big;
+    if (big && nblocks > 2 * chunk && room_to_grow(*c, j, big)) chunk = nblocks - 2 * chunk < big ? nblocks - 2 * chunk : big;
     for (Slot &s : c->slot)
         if ((rc = slot_reserve(j, s, chunk, !pinned_io, !pinned_io)) != CW_OK) return rc;
     // One chunk's kernels on every slot (over whatever its device buffers hold): the codecs' per-stream workspaces -- queues, link
