@@ -21,7 +21,7 @@ cpu_baseline -- that time what uniform noise cannot: the codecs' match/emit path
   corpus_skein512_lz4   BASELINE configs[2]: the in-tree corpora (canterbury + canterbury-large) tiled in HBM, 64 KiB
   corpus_skein256_lz4_4k  the reference's own default pair and block size (hc_sklz4: Skein-256-128 + LZ4 at 4 KiB, run_tests:19)
   corpus_sha256_lzf_4k / _64k   BASELINE configs[3], the reference's hc_shlzf pair (run_tests:20), 4 KiB and 64 KiB
-plus "host_path": the drop-in host-buffer entry point (PCIe-inclusive, never `value`).  After its timed region every leg checks
+plus "host_path" / "host_path_corpus": the drop-in host-buffer entry point over noise and over the corpus (PCIe-inclusive, never `value`).  After its timed region every leg checks
 sampled blocks bit-exact against the oracle ("parity_spot_check") and decodes ALL of its slots on the device, comparing them with
 their input blocks ("roundtrip"); a mismatch aborts the run instead of printing a number.
 """
@@ -402,8 +402,9 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
     return leg, sample
 
 
-def host_path_leg(cw, torch, hash_name, comp_name, bs, nbytes):
-    """The drop-in host-buffer entry point (cw_hash_and_compress_packed over page-locked buffers): PCIe-inclusive, never `value`."""
+def host_path_leg(cw, torch, hash_name, comp_name, bs, nbytes, kind="random"):
+    """The drop-in host-buffer entry point (cw_hash_and_compress_packed over page-locked buffers): PCIe-inclusive, never `value`.
+    kind "corpus": the tiled in-tree corpus instead of noise -- the codec, not the link, bounds that call (chunks grow to 2 GiB)."""
     import ctypes as C
     import numpy as np
     L = cw.lib()
@@ -414,7 +415,7 @@ def host_path_leg(cw, torch, hash_name, comp_name, bs, nbytes):
         return {"error": L.cw_last_error().decode()}
     try:
         dev = torch.empty(nb * bs, dtype=torch.uint8, device="cuda")
-        cw.dev_gen_random(SEED, 0, nb, bs, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        fill_input(cw, torch, kind, dev, 0, nb, bs, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         cw.ops.check(L.cw_dev_download(hs, dev.data_ptr(), nb * bs))
         del dev
@@ -433,7 +434,7 @@ def host_path_leg(cw, torch, hash_name, comp_name, bs, nbytes):
         t = statistics.median(times[1:])   # steady state: buffers the device has mapped before (a service re-uses its staging)
         out_bytes = int(offs[nb])
         return {"entry_point": "cw_hash_and_compress_packed (pinned input and output, three-stage pipeline, one calling thread)",
-                "workload": f"{hash_name}+{comp_name} over {nb} x {bs} B uniform-random blocks in host memory",
+                "workload": f"{hash_name}+{comp_name} over {nb} x {bs} B {'uniform-random' if kind == 'random' else kind} blocks in host memory",
                 "value": round(nb * bs / t / 1e9, 2), "unit": "GB/s", "seconds": round(t, 4), "bytes_in": nb * bs, "bytes_out": out_bytes,
                 "first_pass_GBps": round(nb * bs / times[0] / 1e9, 2),   # the first pass after idle is slower (clocks, link; not page mapping: DESIGN.md 5)
                 "roofline": {"bound": "pcie", "achieved": round(max(nb * bs, out_bytes) / t / 1e9, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
@@ -588,6 +589,7 @@ def main():
             legs.append(leg)
         out["legs"] = legs
         out["host_path"] = host_path_leg(cw, torch, "skein512", "lz4", 65536, 8 << 30)
+        out["host_path_corpus"] = host_path_leg(cw, torch, "skein512", "lz4", 65536, 8 << 30, kind="corpus")
     print(json.dumps(out), flush=True)
 
 
