@@ -872,6 +872,7 @@ int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, i
     HostJob j;
     int dummy = 0;
     if ((rc = host_job_init(j, hash_alg, comp_alg, &dummy, block_bytes, nblocks, &dummy, true)) != CW_OK) return rc;
+    if (!j.do_hash && !j.do_comp) return CW_OK; // (CW_HASH_NONE, CW_COMP_NONE): nothing a batch would allocate
     size_t chunk = pipeline_chunk(block_bytes, nblocks);
     // a batch whose chunks may grow (host_pipeline): buffers, workspaces and lane tables for the grown chunk, so that the growth costs
     // no allocation inside a timed window (18.5 GiB of device memory per calling thread)
@@ -885,13 +886,20 @@ int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, i
     // CW_PREPARE_COLD=1 skips both.
     static const char *cold = getenv("CW_PREPARE_COLD");
     if (cold && cold[0] == '1') return CW_OK;
-    for (Slot &s : c->slot) {
-        rc = dev_fused(s.side, s.fork, s.join, hash_alg, comp_alg, (const uint8_t *)s.src.p, block_bytes, block_bytes, chunk, (uint8_t *)s.dig.p,
-                       (uint8_t *)s.dst.p, j.d_stride, (uint32_t *)s.sizes.p, s.stream);
+    for (Slot &s : c->slot) { // the same predicates as pipe_issue: a hash-only job has no slots, sizes or packed stream to touch
+        if (j.do_comp && j.do_hash)
+            rc = dev_fused(s.side, s.fork, s.join, hash_alg, comp_alg, (const uint8_t *)s.src.p, block_bytes, block_bytes, chunk, (uint8_t *)s.dig.p,
+                           (uint8_t *)s.dst.p, j.d_stride, (uint32_t *)s.sizes.p, s.stream);
+        else if (j.do_comp)
+            rc = dev_compress(comp_alg, (const uint8_t *)s.src.p, block_bytes, block_bytes, chunk, (uint8_t *)s.dst.p, j.d_stride, (uint32_t *)s.sizes.p, s.stream);
+        else
+            rc = dev_hash(hash_alg, (const uint8_t *)s.src.p, block_bytes, block_bytes, chunk, (uint8_t *)s.dig.p, s.stream, false, true);
         if (rc != CW_OK) return rc;
-        hipError_t pe = cw::pack_launch((const uint8_t *)s.dst.p, j.d_stride, (const uint32_t *)s.sizes.p, chunk, (uint8_t *)s.pack.p, (uint64_t *)s.offs.p,
-                                        s.stream);
-        if (pe != hipSuccess) return fail(CW_ERR_HIP, "pack launch: %s", hipGetErrorString(pe));
+        if (j.do_comp) {
+            hipError_t pe = cw::pack_launch((const uint8_t *)s.dst.p, j.d_stride, (const uint32_t *)s.sizes.p, chunk, (uint8_t *)s.pack.p, (uint64_t *)s.offs.p,
+                                            s.stream);
+            if (pe != hipSuccess) return fail(CW_ERR_HIP, "pack launch: %s", hipGetErrorString(pe));
+        }
     }
     void *h = nullptr;
     const size_t wb = (size_t)64 << 20 < chunk * block_bytes ? (size_t)64 << 20 : chunk * block_bytes;

@@ -1,0 +1,90 @@
+"""Round-3 GPU tests: the launch policy's own large-batch parsers pinned DIRECTLY to the oracle, and cw_prepare
+over jobs without a codec or without a hash."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import corpus_file, corpus_large_file, corpus_large_names, corpus_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cw():
+    import torch  # noqa: F401  (one HIP runtime for torch and libcwhc.so)
+    import compute_war_amd as cw
+    cw.init(0)
+    return cw
+
+
+def check(rc):
+    from compute_war_amd._lib import check as _check
+    _check(rc)
+
+
+def _corpus_bytes(nbytes):
+    """The in-tree corpora (whole files, canterbury then canterbury-large) repeated to nbytes, with a block of noise every 37 blocks of 64 KiB so that
+    the batch is not purely periodic and the scan's literal-run path, the LZF hand-back path and the parsers all see work."""
+    data = b"".join(corpus_file(n) for n in corpus_names()) + b"".join(corpus_large_file(n) for n in corpus_large_names())
+    a = np.frombuffer((data * (nbytes // len(data) + 1))[:nbytes], dtype=np.uint8).copy()
+    rng = np.random.default_rng(3)
+    for o in range(5 * 65536, nbytes - 65536, 37 * 65536):
+        a[o:o + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8)
+    return a
+
+
+@pytest.mark.parametrize("comp,hash_name,bs,nb", [("lz4", "skein512", 65536, 16384), ("lz4", "skein", 4096, 65536),
+                                                  ("lzf", "sha256mb", 65536, 16384), ("lzf", "sha256mb", 4096, 65536)])
+def test_default_policy_large_batches_equal_the_oracle_on_every_block(cw, oracle, comp, hash_name, bs, nb):
+    """>= 16 Ki x 64 KiB and >= 64 Ki x 4 KiB corpus batches through the fused entry point at the DEFAULT thresholds (no knob set):
+    every block's size, digest and payload against cw_oracle_hash_and_compress run over the WHOLE batch on the host's threads, and the
+    library must report a lane-per-block kernel among what it launched -- so "lanes == oracle" is direct, not via the wavefront parsers."""
+    import torch
+    a = _corpus_bytes(nb * bs)
+    h = {"skein512": oracle.HASH_SKEIN512, "skein": oracle.HASH_SKEIN256_128, "sha256mb": oracle.HASH_SHA256}[hash_name]
+    c = oracle.COMP_LZ4 if comp == "lz4" else oracle.COMP_LZF
+    _, odig, osz, opay = oracle.hash_and_compress(a, bs, h, c, threads=16, want_payload=True)
+    s = torch.cuda.current_stream().cuda_stream
+    src = torch.from_numpy(a).cuda()
+    stride = (cw.compress_bound(comp, bs) + 15) // 16 * 16
+    db = cw.digest_bytes(hash_name)
+    dst = torch.zeros(nb * stride, dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    dig = torch.zeros((nb, db), dtype=torch.uint8, device="cuda")
+    for _ in range(2):   # twice: the second call runs on warm workspaces and lane tables of the first
+        cw.dev_hash_and_compress(hash_name, comp, src.data_ptr(), bs, nb, dig.data_ptr(), dst.data_ptr(), stride, sizes.data_ptr(), s)
+    torch.cuda.synchronize()
+    names = cw.profile_kernels()["codec"]
+    assert "lanes" in names or "vtab" in names, names
+    hz = sizes.cpu().numpy().astype(np.uint32)
+    bad = np.nonzero(hz != osz)[0]
+    assert bad.size == 0, (names, bad[:8], hz[bad[:8]], osz[bad[:8]])
+    assert np.array_equal(dig.cpu().numpy(), odig)
+    # payload: a digest per block over exactly size bytes, device slots against oracle slots
+    slots = dst.view(nb, stride).cpu().numpy()
+    for i in range(nb):
+        z = int(osz[i])
+        if z and hashlib.blake2b(slots[i, :z].tobytes(), digest_size=16).digest() != hashlib.blake2b(opay[i, :z].tobytes(), digest_size=16).digest():
+            raise AssertionError(f"payload of block {i} differs ({names})")
+    if comp == "lzf":
+        assert int((osz == 0).sum()) > 0   # the noise blocks: "did not fit" verdicts are part of the comparison
+
+
+def test_prepare_without_codec_or_without_hash_then_a_normal_batch(cw, oracle):
+    """cw_prepare(hash, CW_COMP_NONE) used to run the pack kernels over NULL sizes/offsets; (CW_HASH_NONE, lz4) and
+    (NONE, NONE) are valid too.  A normal batch afterwards still equals the oracle."""
+    L = cw.lib()
+    H = {"skein512": cw.HASH_SKEIN512, "skein": cw.HASH_SKEIN256_128, "sha256mb": cw.HASH_SHA256, "none": cw.HASH_NONE}
+    C = {"lz4": cw.COMP_LZ4, "lzf": cw.COMP_LZF, "none": cw.COMP_NONE}
+    for hname, cname in (("skein512", "none"), ("none", "lz4"), ("none", "none"), ("sha256mb", "none"), ("none", "lzf")):
+        check(L.cw_prepare(H[hname], C[cname], 4096, 2048, 0))
+    rng = np.random.default_rng(5)
+    blocks = [corpus_file("alice29.txt")[i * 4096:(i + 1) * 4096] for i in range(24)] + [rng.integers(0, 256, 4096, dtype=np.uint8).tobytes() for _ in range(8)]
+    data = np.frombuffer(b"".join(blocks), dtype=np.uint8)
+    check(L.cw_prepare(H["skein"], C["lz4"], 4096, len(blocks), 0))
+    dig, sizes, payload = cw.hash_and_compress_blocks("skein", "lz4", data, 4096)
+    _, odig, osz, opay = oracle.hash_and_compress(data, 4096, oracle.HASH_SKEIN256_128, oracle.COMP_LZ4, threads=2, want_payload=True)
+    assert np.array_equal(dig, odig) and np.array_equal(sizes, osz)
+    for i in range(len(blocks)):
+        assert payload[i][: int(osz[i])].tobytes() == opay[i, : int(osz[i])].tobytes()
