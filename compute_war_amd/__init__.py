@@ -9,7 +9,7 @@ from ._lib import (COMP_LZ4, COMP_LZF, COMP_NONE, HASH_NONE, HASH_SHA256, HASH_S
                    CwError, lib, lib_path)
 from .ops import (HashOffload, compress_blocks, compress_bound, decompress_blocks, do_decompression, dev_compress, dev_decompress, dev_gen_mixed, dev_gen_random, dev_hash, dev_hash_tree, dev_pack, hash_tree_blocks,
                   dev_hash_and_compress, dev_sum_sizes, digest_bytes, do_compression, do_hashing,
-                  hash_and_compress_blocks, hash_and_compress_packed, hash_blocks, init, profile_enable, profile_kernels, profile_read,
+                  hash_and_compress_blocks, hash_and_compress_packed, hash_blocks, init, profile_enable, profile_kernels, profile_read, tune_reset, tune_set, tuned,
                   set_block_size, set_device, get_device, device_count,
                   shutdown)
 

@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "cw_hash_and_compress_packed", "cw_prepare", "cw_host_alloc", "cw_host_free", "cw_host_register", "cw_host_unregister",
     "cw_dev_hash", "cw_dev_compress", "cw_dev_hash_and_compress", "cw_dev_gen_random", "cw_dev_gen_mixed", "cw_dev_sum_sizes",
     "cw_dev_decompress", "cw_dev_pack", "cw_dev_alloc", "cw_dev_free", "cw_dev_upload", "cw_dev_download", "cw_dev_synchronize", "cw_profile_enable", "cw_profile_read", "cw_profile_kernels",
+    "cw_tune_set", "cw_tune_reset",
     "cw_offload_create", "cw_offload_destroy", "cw_offload_reset", "cw_offload_enqueue", "cw_offload_start",
     "cw_offload_complete", "cw_offload_completed", "cw_offload_state", "cw_offload_error", "cw_offload_do",
     "cw_offload_thread_start", "cw_offload_submit", "cw_offload_thread_stop",
@@ -110,6 +111,7 @@ def lib() -> C.CDLL:
         "cw_dev_download": ([vp, vp, sz], C.c_int), "cw_dev_synchronize": ([], C.c_int),
         "cw_profile_enable": ([C.c_int], None), "cw_profile_read": ([vp, vp, C.c_int], C.c_int),
         "cw_profile_kernels": ([C.c_int, vp, sz], C.c_int),
+        "cw_tune_set": ([C.c_char_p, C.c_char_p], C.c_int), "cw_tune_reset": ([], None),
         "cw_offload_create": ([C.c_int, C.c_int, sz], vp), "cw_offload_destroy": ([vp], None),
         "cw_offload_reset": ([vp, vp, vp, ON_COMPLETE, vp], C.c_int),
         "cw_offload_enqueue": ([vp], C.c_int), "cw_offload_start": ([vp], C.c_int),

@@ -20,7 +20,9 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -232,7 +234,7 @@ int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, 
 {
     hipError_t e;
     ProfScope prof(PROF_HASH, s);
-    static const char *slice_env = getenv("CW_SKEIN_SLICED"); // CW_SKEIN_SLICED=0: always the one-launch hash kernel (profiling knob)
+    const char *slice_env = cw::tune("CW_SKEIN_SLICED"); // CW_SKEIN_SLICED=0: always the one-launch hash kernel (profiling knob)
     if (sliced && !(slice_env && slice_env[0] == '0') && (alg == CW_HASH_SKEIN512 || alg == CW_HASH_SKEIN256_128)) {
         const int nw = alg == CW_HASH_SKEIN512 ? 8 : 4;
         if (cw::skein_sliced_applies(nw, d_src, bb, stride, n, d_dig)) {
@@ -278,6 +280,27 @@ thread_local char t_kernels[2][192] = {"", ""};
 
 } // namespace
 
+// Tuning and test knobs.  A knob's value is what cw_tune_set gave it, else the environment variable of the same name (read once),
+// else unset.  Every launch function asks per call, so a test can run two settings in one process.
+namespace {
+std::mutex tune_lock;
+std::map<std::string, std::string> tune_over;                 // cw_tune_set
+std::map<std::string, std::pair<bool, std::string>> tune_env; // getenv, cached (present?, value)
+} // namespace
+
+const char *cw::tune(const char *key)
+{
+    std::lock_guard<std::mutex> g(tune_lock);
+    auto o = tune_over.find(key);
+    if (o != tune_over.end()) return o->second.c_str();
+    auto e = tune_env.find(key);
+    if (e == tune_env.end()) {
+        const char *v = getenv(key);
+        e = tune_env.emplace(key, std::make_pair(v != nullptr, std::string(v ? v : ""))).first;
+    }
+    return e->second.first ? e->second.second.c_str() : nullptr;
+}
+
 void cw::note_kernels(int kind, const char *names)
 {
     if (kind < 0 || kind > 1) return;
@@ -286,6 +309,21 @@ void cw::note_kernels(int kind, const char *names)
 }
 
 extern "C" {
+
+// ---- knobs (CW_TESTING section of the header) -------------------------------------------------------
+int cw_tune_set(const char *key, const char *value)
+{
+    if (!key || strncmp(key, "CW_", 3) != 0) return fail(CW_ERR_BAD_ARG, "knob names start with CW_");
+    std::lock_guard<std::mutex> g(tune_lock);
+    if (value) tune_over[key] = value;
+    else tune_over.erase(key);
+    return CW_OK;
+}
+void cw_tune_reset(void)
+{
+    std::lock_guard<std::mutex> g(tune_lock);
+    tune_over.clear();
+}
 
 // ---- lifecycle ------------------------------------------------------------------------------------
 int cw_device_count(void)
@@ -401,7 +439,7 @@ static int dev_fused(hipStream_t side, hipEvent_t fork, hipEvent_t join, int has
                      uint8_t *d_digests, uint8_t *d_dst, size_t dst_stride, uint32_t *d_sizes, hipStream_t main_s)
 {
     int rc;
-    static const char *serial = getenv("CW_SERIAL"); // CW_SERIAL=1: both kernels on the caller's stream (profiling knob)
+    const char *serial = cw::tune("CW_SERIAL"); // CW_SERIAL=1: both kernels on the caller's stream (profiling knob)
     if (serial && serial[0] == '1') {
         rc = dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, main_s);
         return rc == CW_OK ? dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, main_s, false, true) : rc;
@@ -715,7 +753,7 @@ void pipe_drain(ThreadCtx &c)
 // thread at 512 MiB.  CW_HOST_CHUNK_MB overrides.
 size_t pipeline_chunk(size_t bb, size_t nblocks)
 {
-    static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
+    const char *ck_env = cw::tune("CW_HOST_CHUNK_MB");
     // 512 MiB: the chunk's kernels cost 8-10 ms whatever its size and do not overlap across chunks, and a chunk of 4 KiB blocks has
     // to be large enough for the lane parsers to run beside the LDS-resident ones (8 GiB of 4 KiB corpus blocks, Skein-256 + LZ4 /
     // SHA-256 + LZF: chunks of 64 MiB 29.5 / 18.8 GB/s, 512 MiB 38.6 / 27.2, 1 GiB 40.0 / 20.8; random data 47 -> 45-47 GB/s)
@@ -754,8 +792,8 @@ constexpr size_t kBigChunkBytes = (size_t)2 << 30;
 // blocks of a grown chunk, or 0 when chunks of this job never grow
 size_t grown_chunk(const HostJob &j, size_t chunk, bool pinned_io)
 {
-    static const char *ck_env = getenv("CW_HOST_CHUNK_MB");
-    static const char *bk_env = getenv("CW_HOST_BIG_CHUNK_MB"); // test knob: the grown chunk's size (and growth although CW_HOST_CHUNK_MB is set)
+    const char *ck_env = cw::tune("CW_HOST_CHUNK_MB");
+    const char *bk_env = cw::tune("CW_HOST_BIG_CHUNK_MB"); // test knob: the grown chunk's size (and growth although CW_HOST_CHUNK_MB is set)
     const bool bk_set = bk_env && atol(bk_env) > 0;
     const size_t big = (bk_set ? (size_t)atol(bk_env) << 20 : kBigChunkBytes) / (j.bb ? j.bb : 1);
     const bool may = (bk_set || !(ck_env && atol(ck_env) > 0)) && j.do_comp && j.bb > 4096 && pinned_io && big > chunk;
@@ -793,7 +831,7 @@ int host_pipeline(HostJob &j)
             size_t n = left < chunk ? left : chunk;
             if (may_grow && seen_in && seen_in / 10 * 9 >= seen_out && left > chunk) // compressible so far (>= 10 % saved)
                 n = left >= 2 * big ? big : left > big ? (left + 1) / 2 : left;
-            static const char *dbg_env = getenv("CW_DEBUG_HOST"); // prints the chunks of a call (tests)
+            const char *dbg_env = cw::tune("CW_DEBUG_HOST"); // prints the chunks of a call (tests)
             if (dbg_env && dbg_env[0] == '1') fprintf(stderr, "cw host pipeline: chunk %zu = %zu blocks of %zu B\n", issued, n, j.bb);
             rc = pipe_issue(c, j, c.slot[k % kSlots], next, n);
             next += n;
@@ -884,7 +922,7 @@ int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, i
     // arrays, the lane parsers' tables -- are allocated here instead of inside the first timed batch, and the device leaves its
     // idle clocks.  Then a few copies each way to wake the link (the first pass after idle ran at 25-29 GB/s against 45.7).
     // CW_PREPARE_COLD=1 skips both.
-    static const char *cold = getenv("CW_PREPARE_COLD");
+    const char *cold = cw::tune("CW_PREPARE_COLD");
     if (cold && cold[0] == '1') return CW_OK;
     for (Slot &s : c->slot) { // the same predicates as pipe_issue: a hash-only job has no slots, sizes or packed stream to touch
         if (j.do_comp && j.do_hash)

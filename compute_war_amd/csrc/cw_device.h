@@ -58,6 +58,9 @@ struct SkeinIV { uint64_t w[8]; };
 // The launch functions note which kernels they used, per calling thread (kind 0 = codec, 1 = hash): cw_profile_kernels
 // hands the names to the caller so that a benchmark reports what ran instead of guessing it from its arguments.
 void note_kernels(int kind, const char *names);
+// Value of a tuning / test knob: what cw_tune_set gave it, else the environment variable of that name, else nullptr.  Asked per call
+// (never cached in a static), so tests sweep settings in one process.  The pointer stays valid until the knob is set again.
+const char *tune(const char *key);
 
 // host: chaining value after the configuration block (Skein_*_Init)
 void skein_compute_iv(int state_words, unsigned hash_bits, SkeinIV *iv, uint64_t tree_info = 0);
@@ -82,6 +85,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream);
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream);
+// LZ4 parser with the table in vector registers (lz4_vtab_kernel.hip): parses blocks of the scan's queue (counters[0] = head,
+// counters[1] = length) while more than `reserve` are left, if at least min_queued were queued
+hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *dst, size_t dst_stride, uint32_t *sizes,
+                           const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t reserve, unsigned waves_per_cu, hipStream_t stream);
 hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, uint8_t *dst,
                              size_t block_bytes, uint32_t *status, hipStream_t stream);
 // packed stream: offsets[i] = sum sizes[0..i) (nblocks + 1 entries); slot i copied to packed + offsets[i] (packed may be NULL)

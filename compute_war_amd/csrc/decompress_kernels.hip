@@ -281,11 +281,11 @@ hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, c
     // x 4,096 11.1 vs 7.8, x 65,536 97.7 vs 7.9; 4 KiB x 512 Ki 109.6 vs 75.5).  Unlike the wavefront decoder, which assembles a
     // block in LDS and only stores it when it decoded cleanly, a lane writes as it goes: the bytes of a block with status 1 are
     // unspecified either way.
-    static const char *dl_env = getenv("CW_DECODE_LANES");
+    const char *dl_env = tune("CW_DECODE_LANES");
     const size_t by_bytes = ((size_t)128 << 20) / block_bytes;
     const size_t lane_min = dl_env ? (size_t)atoi(dl_env) : (by_bytes > 4096 ? by_bytes : 4096);
     if (lane_min && nblocks >= lane_min) {
-        static const char *lw_env = getenv("CW_LANES_WPC");
+        const char *lw_env = tune("CW_LANES_WPC");
         const size_t wpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
         size_t lgrid = (nblocks + 63) / 64;
         if (lgrid > 256 * wpc) lgrid = 256 * wpc;

@@ -1972,6 +1972,7 @@ struct Workspace {
     uint32_t *p = nullptr; size_t cap = 0;
     uint16_t *lane_tabs = nullptr; size_t lane_cap = 0; // tables of the lane-per-block parser: 16 KiB per lane
     hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; // the lane parser's stream beside the caller's
+    hipStream_t side2 = nullptr; hipEvent_t fork2 = nullptr, join2 = nullptr; // the register-table parser's
     std::mutex launch;
 };
 std::mutex ws_lock;
@@ -2007,6 +2008,7 @@ void lz4_release_workspaces()
         if (kv.second.p) (void)hipFree(kv.second.p);
         if (kv.second.lane_tabs) (void)hipFree(kv.second.lane_tabs);
         if (kv.second.side) { (void)hipStreamDestroy(kv.second.side); (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); }
+        if (kv.second.side2) { (void)hipStreamDestroy(kv.second.side2); (void)hipEventDestroy(kv.second.fork2); (void)hipEventDestroy(kv.second.join2); }
     }
     ws_map.clear();
 }
@@ -2017,7 +2019,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536 || nblocks > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
-    static const char *sm_env = getenv("CW_LZ4_STAGE_MAX"); // profiling knob: largest block parsed from an LDS copy
+    const char *sm_env = tune("CW_LZ4_STAGE_MAX"); // profiling knob: largest block parsed from an LDS copy
     // measured on text: 4 KiB 26.0 (staged) vs 22.4 GB/s (global); 8 KiB 18.1 vs 20.6; 16 KiB 11.5 vs 18.7 -- blocks per CU win
     const uint32_t stage_max = sm_env && atoi(sm_env) >= 0 ? (uint32_t)atoi(sm_env) : 4096u;
     const bool staged = n <= (stage_max < kStageMax ? stage_max : kStageMax);
@@ -2043,13 +2045,13 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
 
     if ((e = hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), stream)) != hipSuccess) return e;
     // CW_LZ4_MODE=scan stops after the scan kernel (queued blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
-    static const char *mode = getenv("CW_LZ4_MODE");
+    const char *mode = tune("CW_LZ4_MODE");
     // scan: one wavefront per workgroup, 32 KiB of LDS each -> 5 per CU; the grid-stride loop walks the rest
     const size_t scan_grid = nblocks < 256 * 5 ? nblocks : 256 * 5;
     // CW_LZ4_MODE=generic forces the gather-based scan (profiling knob)
     const bool streamable = ((reinterpret_cast<uintptr_t>(src) | src_stride | n) & 15) == 0 && !(mode && strcmp(mode, "generic") == 0);
     if (streamable) {
-        static const char *wpc_env = getenv("CW_SCAN_WPC"); // scan wavefronts per CU (profiling knob; 4 = all that fit)
+        const char *wpc_env = tune("CW_SCAN_WPC"); // scan wavefronts per CU (profiling knob; 4 = all that fit)
         const size_t wpc = wpc_env && atoi(wpc_env) > 0 ? (size_t)atoi(wpc_env) : 4;
         // power-of-two sizes 4 KiB .. 64 KiB go through the span kernel, 64 KiB of whole blocks per pull; what does not
         // fill a span (and every other size) through the per-block streaming kernel.  CW_LZ4_MODE=stream: the latter only.
@@ -2082,9 +2084,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // Measured on text at 64 KiB: 11.9 GB/s against 14.2 GB/s for the second generation with its 10 blocks per CU -- both
     // are bound by the instruction latency of one sequence's serial chain (tools/parse_stamp.hip), not by candidate
     // traffic, so the extra blocks win; the second generation stays the default.
-    static const char *gen_env = getenv("CW_LZ4_PARSE");
+    const char *gen_env = tune("CW_LZ4_PARSE");
     const bool use_fp = !staged && gen_env && strcmp(gen_env, "fp") == 0;
-    static const char *hw_env = getenv("CW_LZ4_HEADW"); // head batch width of the fingerprint parser (profiling knob: 8, 16, 32)
+    const char *hw_env = tune("CW_LZ4_HEADW"); // head batch width of the fingerprint parser (profiling knob: 8, 16, 32)
     const int headw = hw_env ? atoi(hw_env) : 16;
     if (use_fp) lds = kTabBytes + kFpBytes;
     const size_t per_cu = (160u * 1024u) / lds ? (160u * 1024u) / lds : 1;
@@ -2098,14 +2100,14 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // The kernel looks at the queue length on the device and leaves everything to the wavefront parser below the threshold.
     // CW_LZ4_LANES=0 switches it off, =N sets the threshold (1: every queued block, in the tests); CW_LANES_WPC = its
     // wavefronts per CU, CW_LANES_CONCURRENT=0|1 forces the regime, CW_LANES_RESERVE the blocks left to the wavefronts.
-    static const char *lanes_env = getenv("CW_LZ4_LANES");
+    const char *lanes_env = tune("CW_LZ4_LANES");
     // measured break-even with the wavefront parser on text (GB/s, wavefront parser / lanes): 64 KiB 16 Ki blocks 14.2 / 20.9; 16 KiB 16 Ki
     // blocks 18.3 / 17.4, 24 Ki 18.3 / 20.7; 8 KiB 24 Ki blocks 20.9 / 18.5, 32 Ki 20.4 / 22.7 (on small blocks the wavefront parser
     // is faster and a lane slower per byte: every block starts on an empty table, and has one to zero)
     const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env)
                               : staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : n > 16384 ? 14336u : n > 8192 ? 20480u : 28672u;
     bool lanes_used = false, lanes_beside = false;
-    static const char *lf_env = getenv("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
+    const char *lf_env = tune("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
     const bool lanes_fp = !(lf_env && lf_env[0] == '0');
     // CW_LZ4_LANES_RING: 0 = input from global memory (lz4_lanes_kernel); 1, 2, 4, 8 = the ring form with that many positions per
     // iteration whatever the queue's length.  Unset: the ring form, K chosen ON THE DEVICE by the queue's length -- two launches,
@@ -2117,10 +2119,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     //   [kLaneWideBlocks, ...)             K = 1.  Enough chains to be bound by the memory system's random lines, where the
     //       lines of the speculative second position only cost (64 Ki blocks: 38.3 against 35.6 GB/s).
     //   K = 4 / 8 are never better (16 Ki blocks: 20.0 / 16.4 GB/s): each position adds instructions to every iteration.
-    static const char *lr_env = getenv("CW_LZ4_LANES_RING");
+    const char *lr_env = tune("CW_LZ4_LANES_RING");
     const int lanes_ring = lr_env ? atoi(lr_env) : -1; // -1: by queue length
     if (!use_fp && lane_min && nblocks >= lane_min && n >= 64) {
-        static const char *lw_env = getenv("CW_LANES_WPC");
+        const char *lw_env = tune("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
         size_t lgrid = (nblocks + 63) / 64, lcap = 256 * lwpc;
         // LDS-staged blocks, lanes beside the wavefront parser: lanes for about half of the blocks (2 .. 8 wavefronts per CU).  With
@@ -2137,8 +2139,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             wsp.lane_cap = lgrid * 64;
         }
         // CW_LANES_CONCURRENT=0: one after the other on the caller's stream (the lanes take the whole queue); default: side by side
-        static const char *cc_env = getenv("CW_LANES_CONCURRENT");
-        static const char *rs_env = getenv("CW_LANES_RESERVE");
+        const char *cc_env = tune("CW_LANES_CONCURRENT");
+        const char *rs_env = tune("CW_LANES_RESERVE");
         lanes_beside = cc_env ? cc_env[0] != '0' : staged;
         uint32_t reserve = 0, lmin = lane_min;
         if (lanes_beside) {
@@ -2181,14 +2183,40 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if ((e = hipGetLastError()) != hipSuccess) return e;
         lanes_used = true;
     }
-    static const char *pwpc_env = getenv("CW_PARSE_WPC"); // parse wavefronts per CU (profiling knob; default: all the LDS admits)
+    // The register-table parser (lz4_vtab_kernel.hip): 16 more chains per CU than the LDS admits, no table traffic.  CW_LZ4_VTAB: 0 = off,
+    // 1 = on the caller's stream ahead of the wavefront parser (it takes the whole queue), 2 = beside the wavefront parser on a second
+    // stream, both pulling from the queue; CW_VTAB_MIN = queued blocks from which it runs, CW_VTAB_RESERVE = blocks it leaves to the
+    // others, CW_VTAB_WPC = its wavefronts per CU (at most 16).
+    const char *vt_env = tune("CW_LZ4_VTAB");
+    const int vt_mode = vt_env ? atoi(vt_env) : 0;
+    bool vtab_used = false, vtab_beside = false;
+    if (vt_mode > 0 && !use_fp && n >= 64 && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) == 0) {
+        const char *vm_env = tune("CW_VTAB_MIN"), *vr_env = tune("CW_VTAB_RESERVE"), *vw_env = tune("CW_VTAB_WPC");
+        const uint32_t vmin = vm_env ? (uint32_t)atoi(vm_env) : 1u, vres = vr_env ? (uint32_t)atoi(vr_env) : 0u;
+        const unsigned vwpc = vw_env && atoi(vw_env) > 0 ? (unsigned)atoi(vw_env) : 16u;
+        hipStream_t vs = stream;
+        if (vt_mode == 2) {
+            if (!wsp.side2) {
+                if ((e = hipStreamCreateWithFlags(&wsp.side2, hipStreamNonBlocking)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&wsp.fork2, hipEventDisableTiming)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&wsp.join2, hipEventDisableTiming)) != hipSuccess) return e;
+            }
+            if ((e = hipEventRecord(wsp.fork2, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(wsp.side2, wsp.fork2, 0)) != hipSuccess) return e;
+            vs = wsp.side2;
+            vtab_beside = true;
+        }
+        if ((e = lz4_vtab_launch(src, n, src_stride, nblocks, dst, dst_stride, sizes, queue, counters, vmin, vres, vwpc, vs)) != hipSuccess) return e;
+        vtab_used = true;
+    }
+    const char *pwpc_env = tune("CW_PARSE_WPC"); // parse wavefronts per CU (profiling knob; default: all the LDS admits)
     const size_t pwpc = pwpc_env && atoi(pwpc_env) > 0 ? (size_t)atoi(pwpc_env) : 10;
     const size_t want = 256 * (per_cu > pwpc ? pwpc : per_cu);
     const size_t grid = nblocks < want ? nblocks : want;
     // CW_LZ4_MODE=cut parses with the first-generation (write/read-back) kernel only (profiling knob)
     const bool cut_only = mode && strcmp(mode, "cut") == 0;
     // CW_LZ_FORCE_REDO=1: the exchange kernel hands every block back, as if its lane-order check had failed (test knob)
-    static const char *redo_env = getenv("CW_LZ_FORCE_REDO");
+    const char *redo_env = tune("CW_LZ_FORCE_REDO");
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
     if (!cut_only) {
         if (staged)
@@ -2208,6 +2236,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                                dst_stride, sizes, queue, counters, queue2, force_redo);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (vtab_used && vtab_beside) {
+        if ((e = hipEventRecord(wsp.join2, wsp.side2)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, wsp.join2, 0)) != hipSuccess) return e;
+    }
     if (lanes_used && lanes_beside) { // the redo pass and the caller's later work wait for the lanes too
         if ((e = hipEventRecord(wsp.join, wsp.side)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, wsp.join, 0)) != hipSuccess) return e;
@@ -2221,8 +2253,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                             : lanes_ring == 1 ? "cw::lz4_lanes_ring_kernel<1>" : lanes_ring == 2 ? "cw::lz4_lanes_ring_kernel<2>"
                             : lanes_ring == 4 ? "cw::lz4_lanes_ring_kernel<4>" : lanes_ring == 8 ? "cw::lz4_lanes_ring_kernel<8>"
                             : lanes_fp ? "cw::lz4_lanes_kernel<2>" : "cw::lz4_lanes_kernel<0>"; // (as rocprofv3 prints the instantiations)
-        snprintf(names, sizeof names, "%s + %s%s%s", scan_name, lanes_used ? lname : "",
-                 lanes_used ? (lanes_beside ? " beside " : " (large queues), then ") : "",
+        snprintf(names, sizeof names, "%s + %s%s%s%s", scan_name, vtab_used ? (vtab_beside ? "cw::lz4_vtab_kernel beside " : "cw::lz4_vtab_kernel, then ") : "",
+                 lanes_used ? lname : "", lanes_used ? (lanes_beside ? " beside " : " (large queues), then ") : "",
                  cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
                  : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");
         note_kernels(0, names);

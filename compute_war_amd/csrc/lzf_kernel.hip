@@ -1072,23 +1072,23 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     }
     const size_t grid = nblocks < 256 ? nblocks : 256; // the 128 KiB table admits one workgroup per CU
     // CW_LZF_MODE=cut: write/read-back kernel only; =table: exchange kernel with the 128 KiB table also for small blocks
-    static const char *mode = getenv("CW_LZF_MODE");
+    const char *mode = tune("CW_LZF_MODE");
     const bool cut_only = mode && strcmp(mode, "cut") == 0, table_only = mode && strcmp(mode, "table") == 0;
-    static const char *redo_env = getenv("CW_LZ_FORCE_REDO"); // test knob, see lz4_kernel.hip
+    const char *redo_env = tune("CW_LZ_FORCE_REDO"); // test knob, see lz4_kernel.hip
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
     if (!cut_only && !table_only && n >= 16) {
         // links for a round of blocks, then the chain parser over that round
-        static const char *lm_env = getenv("CW_LZF_LDS_MAX"); // profiling knob: largest block parsed from LDS-resident links
+        const char *lm_env = tune("CW_LZF_LDS_MAX"); // profiling knob: largest block parsed from LDS-resident links
         // measured (text): 4 KiB 13.2 (LDS) vs 12.4 GB/s (global links); 8 KiB 7.2 vs 10.6; 16 KiB 3.7 vs 9.3 -- blocks per CU win
         const uint32_t lds_max = lm_env && atoi(lm_env) > 0 ? (uint32_t)atoi(lm_env) : 4096u;
         const bool big = n > (lds_max < kChainMax ? lds_max : kChainMax);
         const uint32_t n2 = (n + 63u) & ~63u;
         const size_t ws_bytes = big ? (size_t)1 << 30 : (size_t)256 << 20; // links per round
-        static const char *round_env = getenv("CW_LZF_ROUND"); // test knob: blocks per round (many rounds on small data)
-        static const char *lanes_env = getenv("CW_LZF_LANES");
+        const char *round_env = tune("CW_LZF_ROUND"); // test knob: blocks per round (many rounds on small data)
+        const char *lanes_env = tune("CW_LZF_LANES");
         // (blocks of 4-8 KiB: the chain kernels win up to ~18 Ki blocks -- text, 8 KiB, 16 Ki blocks 11.0 against 10.6 GB/s, 24 Ki 11.3 / 13.0)
         const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? (n > 8192 ? kLzfLaneMinBlocks : 18432u) : kLzfLaneMinSmall);
-        static const char *cc_env = getenv("CW_LANES_CONCURRENT");
+        const char *cc_env = tune("CW_LANES_CONCURRENT");
         const bool use_lanes = lane_min && nblocks >= lane_min;
         const bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
         const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? kLzfBesideRound : ws_bytes / (2 * (size_t)n2);
@@ -1123,11 +1123,11 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             if (!w.counter && (e = hipMalloc(reinterpret_cast<void **>(&w.counter), kCtrBytes)) != hipSuccess) return e;
         }
         if (use_lanes) {
-            static const char *lw_env = getenv("CW_LANES_WPC");
+            const char *lw_env = tune("CW_LANES_WPC");
             const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 4;
             size_t lgrid = (nblocks + 63) / 64;
             if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
-            static const char *rs0_env = getenv("CW_LANES_RESERVE");
+            const char *rs0_env = tune("CW_LANES_RESERVE");
             const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
             if (beside && lgrid * 64 + want_reserve > nblocks) lgrid = nblocks > want_reserve + 64 ? (nblocks - want_reserve) / 64 : 1; // (no lane without a block)
             LinkSpace &w = entry->s;
@@ -1153,7 +1153,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                     if ((e = hipEventCreateWithFlags(&w.fork, hipEventDisableTiming)) != hipSuccess) return e;
                     if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
                 }
-                static const char *rs_env = getenv("CW_LANES_RESERVE");
+                const char *rs_env = tune("CW_LANES_RESERVE");
                 lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
                 if (lane_reserve < 1) lane_reserve = 1; // (0 means "on their own" to the kernel; the protocol itself needs no reserve)
                 if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
@@ -1209,7 +1209,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             if (e == hipSuccess) e = hipStreamWaitEvent(stream, ls.join, 0);
             if (e != hipSuccess) return e;
         }
-        if (use_lanes && getenv("CW_DEBUG_LZF")) {
+        if (use_lanes && tune("CW_DEBUG_LZF")) {
             uint32_t h[kCtrBytes / 4];
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(h, ls.counter, kCtrBytes, hipMemcpyDeviceToHost);

@@ -493,7 +493,7 @@ hipError_t skein_sliced_launch(int nw, const uint8_t *src, size_t block_bytes, s
                                uint8_t *digests, unsigned digest_bytes, hipStream_t stream)
 {
     const size_t bb = (size_t)nw * 8, total = block_bytes / bb + 1, spl = 128 / bb;
-    static const char *ns_env = getenv("CW_SKEIN_NSLICES"); // profiling knob
+    const char *ns_env = tune("CW_SKEIN_NSLICES"); // profiling knob
     const size_t nsl = ns_env && atoi(ns_env) > 0 ? (size_t)atoi(ns_env) : kSkeinSlices;
     size_t slice_steps = (total + nsl - 1) / nsl;
     slice_steps = (slice_steps + spl - 1) / spl * spl;
@@ -660,7 +660,7 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
     // beside codec wavefronts the step kernel keeps 4 instead of 3 hash wavefronts per SIMD, which helped at 512 Ki
     // blocks (32.7 vs 36-42 ms) and made no difference at 1 Mi blocks (68 vs 69 ms), so callers do not ask for it
     // (`lean` stays false); CW_SKEIN_MODE=steps|lines overrides (profiling knob).
-    static const char *mode = getenv("CW_SKEIN_MODE");
+    const char *mode = tune("CW_SKEIN_MODE");
     const bool steps = mode ? strcmp(mode, "steps") == 0 : lean;
     if (aligned && !ragged && steps) CW_LAUNCH(true, false);
     else if (aligned && !ragged) CW_LAUNCH_LINES(true);

@@ -251,6 +251,32 @@ def profile_read(reset: bool = True) -> dict:
     return {k: (ms[i], cnt[i]) for i, k in enumerate(("codec", "hash", "other"))}
 
 
+def tune_set(key: str, value=None) -> None:
+    """cw_tune_set: a knob's value for the calls that follow (None removes the override; the environment stays the default)."""
+    check(lib().cw_tune_set(key.encode(), None if value is None else str(value).encode()))
+
+
+def tune_reset() -> None:
+    lib().cw_tune_reset()
+
+
+class tuned:
+    """with tuned(CW_LZ4_LANES=1, ...): the knobs hold inside the block and are removed afterwards."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            tune_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.knobs:
+            tune_set(k, None)
+        return False
+
+
 def profile_kernels() -> dict:
     """Names of the kernels the calling thread's latest codec / hash launch used (as rocprofv3 prints them)."""
     out = {}

@@ -196,6 +196,15 @@ int  cw_profile_read(double ms_sum[3], unsigned count[3], int reset);   /* synch
 /* names of the kernels the calling thread's latest codec (kind 0) / hash (kind 1) launch used, as rocprofv3 prints them */
 int  cw_profile_kernels(int kind, char *buf, size_t cap);
 
+/* ---- CW_TESTING: tuning and test knobs -----------------------------------------------------------------------------
+ * Every knob the launch policy reads (thresholds such as CW_LZ4_LANES / CW_LZF_LANES / CW_LZ4_VTAB, CW_LANES_*, CW_LZF_ROUND,
+ * CW_LZ_FORCE_REDO, CW_DECODE_LANES, CW_HOST_*CHUNK_MB, ...; DESIGN.md lists them) is looked up PER CALL: the value given
+ * here wins, the environment variable of the same name is the default.  value = NULL removes an override.  Not part of the
+ * reference's interface (it has no tunables beyond its CLI); meant for tests and profiling, and not to be changed while
+ * other threads are inside compute calls.                                                                             */
+int  cw_tune_set(const char *key, const char *value);
+void cw_tune_reset(void);
+
 /* ---- HashOffload (HashOffload.h:13-64): batch object + the offload thread that drains it -------
  * Lifecycle  hInit --Enqueue--> hQueued --Start--> hOffloaded --Complete--> hComplete.
  * Start() = "xfer data, load kernel" (:26-31): async H2D + hash kernel + async D2H on the object's stream.
