@@ -88,14 +88,24 @@ __device__ __forceinline__ void sc_wait(u32x8 &a) { asm volatile("s_waitcnt lgkm
 __device__ __forceinline__ void sc_wait(u32x8 &a, u32x8 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 
 // A Window is the 32 bytes loaded for position q from byte offset (q & ~3) - 4: `before` = bytes [q-4, q), `at` = [q, q+4),
-// `after` = [q+4, q+12), `after2` = [q+12, q+20).
+// `after` = [q+4, q+12), `after2` = [q+12, q+20).  For q < 4 the load starts at offset 0 (an offset that wrapped below zero makes the
+// whole load read as zero: tools/sbuf.hip) and win_ready moves the dwords up by one, so that the accessors stay the same.
 struct Window { u32x8 d; uint32_t sh; };
 __device__ __forceinline__ Window win_load(const u32x4 &rs, uint32_t q)
 {
     Window w;
-    w.d = sc_load32(rs, (q & ~3u) - 4u);
+    const uint32_t q4 = q & ~3u;
+    w.d = sc_load32(rs, q4 ? q4 - 4u : 0u);
     w.sh = (q & 3u) * 8u;
     return w;
+}
+// after the wait: bring a window loaded for a position below 4 into the common layout (`before` then holds [0, q) in its top bytes)
+__device__ __forceinline__ void win_ready(Window &w, uint32_t q)
+{
+    if (q < 4) { // rare (the block's first probes, empty table slots): a real branch, not seven conditional moves on every window
+        asm volatile("" : "+s"(w.d));
+        w.d[7] = w.d[6]; w.d[6] = w.d[5]; w.d[5] = w.d[4]; w.d[4] = w.d[3]; w.d[3] = w.d[2]; w.d[2] = w.d[1]; w.d[1] = w.d[0]; w.d[0] = 0;
+    }
 }
 __device__ __forceinline__ uint32_t fun32(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
 __device__ __forceinline__ uint32_t win_before(const Window &w) { return fun32(w.d[0], w.d[1], w.sh); }
@@ -108,18 +118,12 @@ __device__ __forceinline__ uint64_t win_after2(const Window &w)
 {
     return (uint64_t)fun32(w.d[4], w.d[5], w.sh) | ((uint64_t)fun32(w.d[5], w.d[6], w.sh) << 32);
 }
-// 4 bytes at q - 2 of the window loaded for q
+// 4 bytes at q - 2 of the window loaded for q (q >= 2)
 __device__ __forceinline__ uint32_t win_at_m2(const Window &w)
 {
     // byte offset of q-2 inside the window: 2 + (q & 3) = 2..5
     const uint32_t s2 = w.sh + 16u;
     return s2 < 32u ? fun32(w.d[0], w.d[1], s2) : fun32(w.d[1], w.d[2], s2 - 32u);
-}
-// 4 bytes at q + 1
-__device__ __forceinline__ uint32_t win_at_p1(const Window &w)
-{
-    const uint32_t s2 = w.sh + 8u; // 8..32
-    return s2 < 32u ? fun32(w.d[1], w.d[2], s2) : w.d[2];
 }
 
 __device__ __forceinline__ uint32_t hash13(uint32_t v) { return (v * 2654435761u) >> 19; }
@@ -201,6 +205,7 @@ lz4_vtab_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
         if (n >= kMFLimit + 1) {
             Window wp = win_load(rs, ip);
             sc_wait(wp.d);
+            win_ready(wp, ip);
             for (;;) { // one sequence per iteration
                 // ---- search: probe ip, ip+1, ... with a stride that grows every 64 misses ----
                 uint32_t cur, cand;
@@ -218,6 +223,8 @@ lz4_vtab_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
                         wc = win_load(rs, cand);
                         Window wn = win_load(rs, fip);
                         sc_wait(wc.d, wn.d);
+                        win_ready(wc, cand);
+                        win_ready(wn, fip);
                         if (win_at(wc) == v) { found = true; break; }
                         wp = wn;
                     }
@@ -314,6 +321,7 @@ lz4_vtab_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
                     wc = win_load(rs, cand);
                     Window wn = win_load(rs, ip + 1);
                     sc_wait(wc.d, wn.d);
+                    win_ready(wc, cand);
                     if (win_at(wc) == v) { cur = ip; back = 0; lit = 0; continue; }
                     wp = wn;
                     ip += 1;

@@ -67,25 +67,39 @@ constexpr uint32_t kRedo = 0xFFFFFFFFu; // sizes[] marker: exchange kernel -> wr
 // once and meet the rounds.  `reserve` (how many unclaimed blocks the lanes leave alone) is a matter of speed only.
 // ctr == nullptr: no lanes beside (the rounds take everything).
 // counter block of a stream's workspace (dword indices; each group on a 128-byte line of its own -- they are hammered by different
-// parties): [0] the round's pull counter, [32..33] W, [64] poor, [65] fine, [66] handed back, [96..97] published
-constexpr uint32_t kCtrWord = 32, kCtrPoor = 64, kCtrFine = 65, kCtrHanded = 66, kCtrPublished = 96, kCtrBytes = 512;
-struct LaneShare { uint32_t *ctr; size_t round_first, total; uint32_t seq; };
+// parties): [0] the round's pull counter, [32..33] W, [64] poor, [65] fine, [66] handed back, [96..97] published, [98] claim ticket,
+// [99] failed
+constexpr uint32_t kCtrWord = 32, kCtrPoor = 64, kCtrFine = 65, kCtrHanded = 66, kCtrPublished = 96, kCtrTicket = 98, kCtrFailed = 99, kCtrBytes = 512;
+constexpr uint32_t kShareGaveUp = 0xFFFFFFFFu; // share_round_taken: the published number never came (see there)
+constexpr uint32_t kShareSpinCap = 1u << 20;   // polls of ~64 cycles: tens of milliseconds, against the microsecond a claim takes
+struct LaneShare { uint32_t *ctr; size_t round_first, total; uint32_t seq, spin_cap; };
 __device__ __forceinline__ unsigned long long *share_word(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + kCtrWord); }
 __device__ __forceinline__ unsigned long long *share_published(uint32_t *ctr) { return reinterpret_cast<unsigned long long *>(ctr + kCtrPublished); }
 __device__ __forceinline__ bool lanes_took(const LaneShare &sh, uint32_t taken, size_t blk)
 {
     return sh.ctr && sh.round_first + blk >= sh.total - taken;
 }
-// the lanes' `taken` as of this round's claim (claim == true: the round's first kernel; every lane of the grid calls it)
+// The lanes' `taken` as of this round's claim (claim == true: the round's first kernel; every lane of the grid calls it).
+// The claim is made by whichever workgroup of the round's first kernel ARRIVES first (a ticket moved from seq - 1 to seq with one
+// compare-and-swap: rounds run in stream order, so the ticket of round seq - 1 is final when round seq starts) -- no assumption
+// about which workgroup the dispatcher starts first: the others wait for a workgroup that is, by construction, running and a
+// few instructions away from publishing.  The wait is bounded all the same: after spin_cap polls the caller gets kShareGaveUp,
+// the batch's `failed` word is set and the caller leaves its blocks alone; the final lzf_blocks_kernel pass then parses EVERY
+// block of the batch again (slow and exact), as it does for blocks whose lane-order check failed.  (spin_cap = 0 forces that path
+// for every workgroup but the claimant: CW_LZF_SHARE_GIVE_UP=1, a test knob.)
 __device__ __forceinline__ uint32_t share_round_taken(const LaneShare &sh, size_t nblocks, bool claim)
 {
     unsigned long long *pub = share_published(sh.ctr);
-    if (claim && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (claim && threadIdx.x == 0 && atomicCAS(sh.ctr + kCtrTicket, sh.seq - 1, sh.seq) == sh.seq - 1) {
         const unsigned long long old = atomicAdd(share_word(sh.ctr), (unsigned long long)nblocks << 32);
         __hip_atomic_store(pub, ((unsigned long long)sh.seq << 32) | (uint32_t)old, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned long long p = __hip_atomic_load(pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    while ((uint32_t)(p >> 32) != sh.seq) { // (workgroup 0 is dispatched first: it is running)
+    for (uint32_t polls = 0; (uint32_t)(p >> 32) != sh.seq; polls++) {
+        if (polls >= sh.spin_cap) {
+            if (threadIdx.x == 0) __hip_atomic_store(sh.ctr + kCtrFailed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return kShareGaveUp;
+        }
         __builtin_amdgcn_s_sleep(2);
         p = __hip_atomic_load(pub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -133,8 +147,10 @@ __device__ __forceinline__ void put_literals(uint8_t *__restrict__ out, const ui
 
 __global__ void __launch_bounds__(64)
 lzf_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks,
-                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t in_lds, uint32_t only_marked)
+                  uint8_t *__restrict__ dst, size_t dst_stride, uint32_t *__restrict__ sizes, uint32_t in_lds, uint32_t only_marked, const uint32_t *__restrict__ failed)
 {
+    // failed: the batch's "a round's claim was never seen" word (share_round_taken): set => every block is parsed again here
+    const bool everything = failed && __builtin_amdgcn_readfirstlane(*failed) != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
     uint8_t *stage = smem + kLzfTabBytes;
@@ -144,7 +160,7 @@ lzf_blocks_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride
     for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         // second pass behind lzf_parse_kernel: only the blocks it handed back (none, unless the LDS ever applies the
         // lanes of an exchange out of order)
-        if (only_marked && __builtin_amdgcn_readfirstlane(sizes[blk]) != kRedo) continue;
+        if (only_marked && !everything && __builtin_amdgcn_readfirstlane(sizes[blk]) != kRedo) continue;
         const uint8_t *g = src + blk * src_stride;
         uint8_t *out = dst + blk * dst_stride;
 
@@ -487,7 +503,7 @@ lzf_links_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     uint32_t taken = 0;
     if (share.ctr) { // claim this round's blocks and learn what the lanes held at that instant
         taken = share_round_taken(share, nblocks, true);
-        if (share.round_first >= share.total - taken) return; // the whole round is theirs
+        if (taken == kShareGaveUp || share.round_first >= share.total - taken) return; // (gave up: the final pass parses the batch) the whole round is theirs
     }
     // LDS: the 128 KiB table, then the block (coalesced copy; positions are then read as aligned dwords)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -613,7 +629,7 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     uint32_t taken = 0;
     if (share.ctr) { // (the round is claimed: its links kernel ran and published)
         taken = share_round_taken(share, nblocks, false);
-        if (share.round_first >= share.total - taken) return;
+        if (taken == kShareGaveUp || share.round_first >= share.total - taken) return;
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *E = reinterpret_cast<uint16_t *>(smem);          // !BIG: link | kSkipFlag, n2 entries
@@ -1184,10 +1200,12 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if (per_cu > (big ? 20u : 16u)) per_cu = big ? 20 : 16;
         // one round of the link + chain kernels: blocks [first, first + nb) of the batch, or entries [first, first + nb) of the
         // hand-back list (as far as the lanes filled it: the kernels read its length on the device and return at once beyond it)
+        const char *gu_env = tune("CW_LZF_SHARE_GIVE_UP"); // test knob: every workgroup but a round's claimant gives up at once
+        const uint32_t spin_cap = gu_env && atoi(gu_env) > 0 ? 0u : kShareSpinCap;
         auto round = [&](size_t first, size_t nb, bool listed) -> hipError_t {
             hipError_t r = hipMemsetAsync(ls.counter, 0, sizeof(uint32_t), stream);
             if (r != hipSuccess) return r;
-            const LaneShare share = {beside && !listed ? ls.counter : nullptr, first, nblocks, (uint32_t)(first / chunk + 1)};
+            const LaneShare share = {beside && !listed ? ls.counter : nullptr, first, nblocks, (uint32_t)(first / chunk + 1), spin_cap};
             const BlockList list = {listed ? ls.handback : nullptr, listed ? ls.counter + kCtrHanded : nullptr, (uint32_t)first};
             const size_t off = listed ? 0 : first; // listed blocks are addressed through the list, from the batch's base
             hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, src + off * src_stride, n,
@@ -1213,14 +1231,14 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             uint32_t h[kCtrBytes / 4];
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(h, ls.counter, kCtrBytes, hipMemcpyDeviceToHost);
-            fprintf(stderr, "lzf lanes: taken %u claimed %u poor %u fine %u handed back %u of %zu\n", h[kCtrWord], h[kCtrWord + 1], h[kCtrPoor],
-                    h[kCtrFine], h[kCtrHanded], nblocks);
+            fprintf(stderr, "lzf lanes: taken %u claimed %u poor %u fine %u handed back %u of %zu; claim ticket %u, gave up %u\n", h[kCtrWord],
+                    h[kCtrWord + 1], h[kCtrPoor], h[kCtrFine], h[kCtrHanded], nblocks, h[kCtrTicket], h[kCtrFailed]);
         }
         if (use_lanes)
             for (size_t first = 0; first < nblocks; first += hb_chunk)
                 if ((e = round(first, nblocks - first < hb_chunk ? nblocks - first : hb_chunk, true)) != hipSuccess) return e;
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                           dst_stride, sizes, in_lds, 1u);
+                           dst_stride, sizes, in_lds, 1u, beside ? ls.counter + kCtrFailed : nullptr);
         note_kernels(0, beside ? (big ? "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<true>"
                                       : n <= 4096 ? "cw::lzf_lanes_kernel<true> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>"
                                                   : "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>")
@@ -1241,7 +1259,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                       dst_stride, sizes, in_lds, cut_only ? 0u : 1u);
+                       dst_stride, sizes, in_lds, cut_only ? 0u : 1u, static_cast<const uint32_t *>(nullptr));
     note_kernels(0, cut_only ? "cw::lzf_blocks_kernel" : in_lds ? "cw::lzf_parse_kernel<true>" : "cw::lzf_parse_kernel<false>");
     return hipGetLastError();
 }

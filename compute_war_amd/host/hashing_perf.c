@@ -10,7 +10,12 @@
  *
  * Each timed region is one synchronous call through the slot-compatible entry points (H2D + kernel + D2H), i.e.
  * the latency a caller of the reference's functions would see; blocks are whole 4 KiB blocks, a partial tail is
- * dropped (file.cpp:18-60).  Usage: hashing_perf <data-dir>   (test.cpp:68-73)
+ * dropped (file.cpp:18-60).  Usage: hashing_perf [--verify] <data-dir>   (test.cpp:68-73)
+ *
+ * --verify (not in the reference, whose harness never looks at a digest: test.cpp:7-29): after the log, one line per algorithm
+ *   verify|<alg>|<digests>|<xor-fold of all digests as 64-bit words>
+ * the fold hashandcompress -v prints (Skein256: the single-block calls; Sha256: the single-block calls; Sha256MB: every window
+ * of every window size), so the harness's results can be checked against the oracle, not only its format.
  */
 #define _GNU_SOURCE
 #include <dirent.h>
@@ -25,6 +30,17 @@
 
 #define LOG_SEPARATOR "|"
 enum { kBlockSize = 4096 }; /* shared.h:25 */
+
+static int verify = 0;
+static uint64_t fold_sk = 0, fold_sha = 0, fold_mb = 0, n_sk = 0, n_sha = 0, n_mb = 0;
+static void fold_digests(const uint8_t *d, size_t bytes, uint64_t *acc)
+{
+    for (size_t i = 0; i + 8 <= bytes; i += 8) {
+        uint64_t v;
+        memcpy(&v, d + i, 8);
+        *acc ^= v;
+    }
+}
 
 static uint64_t now_us(void)
 {
@@ -60,11 +76,13 @@ static void run_sb(const char *file, const uint8_t *blocks, size_t n)
         uint64_t t1 = now_us();
         printf("%s" LOG_SEPARATOR "%llu" LOG_SEPARATOR "Skein256" LOG_SEPARATOR "%llu" LOG_SEPARATOR "\n", file,
                (unsigned long long)index++, (unsigned long long)(t1 - t0));
+        if (verify) { fold_digests(digest, 16, &fold_sk); n_sk++; }
         t0 = now_us();
         cw_hash_sha256mb(b, (char *)digest, 1); /* HashBlockSHA256 (hash.cpp:28-46) */
         t1 = now_us();
         printf("%s" LOG_SEPARATOR "%llu" LOG_SEPARATOR "Sha256" LOG_SEPARATOR "%llu" LOG_SEPARATOR "\n", file,
                (unsigned long long)index++, (unsigned long long)(t1 - t0));
+        if (verify) { fold_digests(digest, 32, &fold_sha); n_sha++; }
     }
 }
 
@@ -79,6 +97,7 @@ static void run_mb(const char *file, const uint8_t *blocks, size_t n, size_t win
         uint64_t t1 = now_us();
         printf("%s" LOG_SEPARATOR "%llu" LOG_SEPARATOR "Sha256MB" LOG_SEPARATOR "%llu" LOG_SEPARATOR "%llu" LOG_SEPARATOR "\n", file,
                (unsigned long long)w, (unsigned long long)(t1 - t0), (unsigned long long)window);
+        if (verify) { fold_digests(digests, 32 * window, &fold_mb); n_mb += window; }
     }
     free(digests);
 }
@@ -108,8 +127,9 @@ static void walk(const char *dir)
 
 int main(int argc, char **argv)
 {
+    if (argc == 3 && strcmp(argv[1], "--verify") == 0) { verify = 1; argv++; argc--; }
     if (argc != 2) { /* ASSERT_OP(argc, ==, 2) (test.cpp:70) */
-        fprintf(stderr, "Usage: %s <data-dir>\n", argv[0]);
+        fprintf(stderr, "Usage: %s [--verify] <data-dir>\n", argv[0]);
         return 1;
     }
     if (cw_init(0) != CW_OK) {
@@ -118,6 +138,11 @@ int main(int argc, char **argv)
     }
     cw_set_block_size(kBlockSize);
     walk(argv[1]);
+    if (verify) {
+        printf("verify" LOG_SEPARATOR "Skein256" LOG_SEPARATOR "%llu" LOG_SEPARATOR "%016llx\n", (unsigned long long)n_sk, (unsigned long long)fold_sk);
+        printf("verify" LOG_SEPARATOR "Sha256" LOG_SEPARATOR "%llu" LOG_SEPARATOR "%016llx\n", (unsigned long long)n_sha, (unsigned long long)fold_sha);
+        printf("verify" LOG_SEPARATOR "Sha256MB" LOG_SEPARATOR "%llu" LOG_SEPARATOR "%016llx\n", (unsigned long long)n_mb, (unsigned long long)fold_mb);
+    }
     cw_shutdown();
     return 0;
 }

@@ -59,13 +59,29 @@ def test_driver_usage_errors():
     assert r.returncode == 1 and "invalid hashing algorithm" in r.stderr
 
 
-def test_hashing_perf_log_format(tmp_path):
+def _fold(digests: bytes) -> int:
+    import numpy as np
+    return int(np.bitwise_xor.reduce(np.frombuffer(digests, dtype="<u8"))) if digests else 0
+
+
+def test_hashing_perf_log_format(tmp_path, oracle):
     d = tmp_path / "data"
     d.mkdir()
-    (d / "a.bin").write_bytes(corpus_file("alice29.txt")[:5 * 4096 + 100])
-    r = subprocess.run([PERF, str(d)], capture_output=True, text=True, timeout=300)
+    data = corpus_file("alice29.txt")[:5 * 4096 + 100]
+    (d / "a.bin").write_bytes(data)
+    r = subprocess.run([PERF, "--verify", str(d)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
+    # --verify: the XOR fold of every digest the harness computed, against the oracle's digests of the same blocks
+    blocks = [data[i * 4096:(i + 1) * 4096] for i in range(5)]
+    sk = b"".join(oracle.skein256(b, 128) for b in blocks)
+    sha = b"".join(oracle.sha256(b) for b in blocks)
+    mb = b"".join(b"".join(oracle.sha256(b) for b in blocks[: 5 // w * w]) for w in range(1, 65))
+    ver = {l.split("|")[1]: l.split("|")[2:] for l in lines if l.startswith("verify|")}
+    assert ver["Skein256"] == ["5", "%016x" % _fold(sk)]
+    assert ver["Sha256"] == ["5", "%016x" % _fold(sha)]
+    assert ver["Sha256MB"] == [str(sum(5 // w * w for w in range(1, 65))), "%016x" % _fold(mb)]
+    lines = [l for l in lines if not l.startswith("verify|")]
     sb = [l for l in lines if "|Skein256|" in l or "|Sha256|" in l]
     mb = [l for l in lines if "|Sha256MB|" in l]
     assert len(sb) == 10                                   # 5 whole blocks x 2 algorithms (test.cpp:19-23)

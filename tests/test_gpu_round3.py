@@ -88,3 +88,30 @@ def test_prepare_without_codec_or_without_hash_then_a_normal_batch(cw, oracle):
     assert np.array_equal(dig, odig) and np.array_equal(sizes, osz)
     for i in range(len(blocks)):
         assert payload[i][: int(osz[i])].tobytes() == opay[i, : int(osz[i])].tobytes()
+
+
+def test_lzf_lane_share_claim_that_is_never_seen_ends_in_an_exact_batch(cw, oracle, capfd):
+    """The rounds' workgroups wait (bounded) for the round's claim to be published (LaneShare, lzf_kernel.hip).  CW_LZF_SHARE_GIVE_UP=1
+    makes every workgroup but the claimant give up at once: the batch's `gave up` word must be set, and the final pass must then parse
+    every block again -- sizes and payloads equal the oracle's all the same, no hang.  Without the knob nobody gives up."""
+    import torch
+    bs, nb = 4096, 32768      # LZF lanes BESIDE the link/chain rounds start at 28 Ki blocks of <= 4 KiB
+    a = _corpus_bytes(nb * bs)
+    _, _, osz, opay = oracle.hash_and_compress(a, bs, oracle.HASH_NONE, oracle.COMP_LZF, threads=16, want_payload=True)
+    s = torch.cuda.current_stream().cuda_stream
+    src = torch.from_numpy(a).cuda()
+    stride = (cw.compress_bound("lzf", bs) + 15) // 16 * 16
+    for give_up in (1, 0):
+        dst = torch.zeros(nb * stride, dtype=torch.uint8, device="cuda")
+        sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        with cw.tuned(CW_LZF_SHARE_GIVE_UP=give_up, CW_DEBUG_LZF=1):
+            cw.dev_compress("lzf", src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert "beside" in cw.profile_kernels()["codec"]
+        err = capfd.readouterr().err
+        assert ("gave up 1" in err) == bool(give_up), err[-400:]
+        assert np.array_equal(sizes.cpu().numpy().astype(np.uint32), osz)
+        slots = dst.view(nb, stride).cpu().numpy()
+        for i in range(0, nb, 7):
+            z = int(osz[i])
+            assert slots[i, :z].tobytes() == opay[i, :z].tobytes(), i
