@@ -270,7 +270,7 @@ int dev_compress(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t
     return CW_OK;
 }
 
-thread_local char t_kernels[2][192] = {"", ""};
+thread_local char t_kernels[2][320] = {"", ""};
 
 [[noreturn]] void die(const char *what)
 {

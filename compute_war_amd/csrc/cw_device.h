@@ -86,9 +86,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream);
 // LZ4 parser with the table in vector registers (lz4_vtab_kernel.hip): parses blocks of the scan's queue (counters[0] = head,
-// counters[1] = length) while more than `reserve` are left, if at least min_queued were queued
+// counters[1] = length) while more than `reserve` are left, if the queue's length lies in [min_queued, max_queued)
 hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *dst, size_t dst_stride, uint32_t *sizes,
-                           const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t reserve, unsigned waves_per_cu, hipStream_t stream);
+                           const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t max_queued, uint32_t reserve,
+                           unsigned waves_per_cu, hipStream_t stream, const char **kernel_name);
 hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, uint8_t *dst,
                              size_t block_bytes, uint32_t *status, hipStream_t stream);
 // packed stream: offsets[i] = sum sizes[0..i) (nblocks + 1 entries); slot i copied to packed + offsets[i] (packed may be NULL)

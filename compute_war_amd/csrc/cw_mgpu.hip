@@ -96,9 +96,11 @@ cw_mgpu_t *cw_mgpu_create(const int *devices, int ndev)
         for (int k = 0; k < i; k++)
             if (devices[i] == devices[k]) { snprintf(t_mgpu_err, sizeof t_mgpu_err, "cw_mgpu_create: device %d listed twice", devices[i]); return nullptr; }
     const int before = cw_get_device();
+    // every exit path leaves the calling thread on the device it came with (cw_init and hipSetDevice below switch it)
+    auto back = [&]() { if (before >= 0) (void)cw_set_device(before); };
     for (int i = 0; i < ndev; i++)
-        if (cw_init(devices[i]) != CW_OK) { snprintf(t_mgpu_err, sizeof t_mgpu_err, "%s", cw_last_error()); return nullptr; }
-    if (!load_rccl()) return nullptr;
+        if (cw_init(devices[i]) != CW_OK) { snprintf(t_mgpu_err, sizeof t_mgpu_err, "%s", cw_last_error()); back(); return nullptr; }
+    if (!load_rccl()) { back(); return nullptr; }
     cw_mgpu *m = new cw_mgpu;
     m->devices.assign(devices, devices + ndev);
     m->comms.assign((size_t)ndev, nullptr);
@@ -107,12 +109,14 @@ cw_mgpu_t *cw_mgpu_create(const int *devices, int ndev)
     if (r != ncclSuccess) {
         snprintf(t_mgpu_err, sizeof t_mgpu_err, "ncclCommInitAll: %s", g_rccl.GetErrorString(r));
         delete m;
+        back();
         return nullptr;
     }
     for (int i = 0; i < ndev; i++) {
         if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&m->streams[(size_t)i], hipStreamNonBlocking) != hipSuccess) {
             snprintf(t_mgpu_err, sizeof t_mgpu_err, "stream on device %d: %s", devices[i], hipGetErrorString(hipGetLastError()));
             cw_mgpu_destroy(m);
+            back();
             return nullptr;
         }
     }
@@ -140,6 +144,7 @@ int cw_mgpu_gather(cw_mgpu_t *m, const void *const *d_local, size_t bytes_each, 
     const int G = (int)m->devices.size();
     const int before = cw_get_device();
     ncclResult_t r = g_rccl.GroupStart();
+    const bool grouped = r == ncclSuccess; // a group that never opened must not be closed
     for (int g = 0; g < G && r == ncclSuccess; g++) {
         if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess) { r = ncclUnhandledCudaError; break; }
         if (bytes_each && d_local && d_all)
@@ -147,8 +152,10 @@ int cw_mgpu_gather(cw_mgpu_t *m, const void *const *d_local, size_t bytes_each, 
         if (r == ncclSuccess && ntotals && d_totals)
             r = g_rccl.AllReduce(d_totals[g], d_totals[g], ntotals, ncclUint64, ncclSum, m->comms[(size_t)g], m->streams[(size_t)g]);
     }
-    const ncclResult_t re = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = re;
+    if (grouped) {
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = re;
+    }
     hipError_t he = hipSuccess;
     for (int g = 0; g < G; g++) {
         (void)hipSetDevice(m->devices[(size_t)g]);

@@ -1402,7 +1402,11 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // ---------------------------------------------------------------------------------------------------
 // blocks > 4 KiB: below kLaneMidBlocks queued blocks the wavefront-per-block parser's 13-14 GB/s win; [mid, wide): lanes with two
 // positions per iteration (every lane holds one block: latency regime), from kLaneWideBlocks on one (random-line regime); lz4_launch
-constexpr uint32_t kLaneMidBlocks = 10240, kLaneWideBlocks = 49152; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
+// Round 3: below kLaneMidBlocks the register-table parser beside the wavefront parser wins (corpus, 64 KiB: 12 Ki / 16 Ki / 24 Ki / 28 Ki blocks
+// 23.9 / 25.1 / 26.1 / 26.5 GB/s against the lanes' 15.4 / 19.5 / 24.1 / 28.8), so the lanes start later than in round 2 (10,240), and from there on
+// they run BESIDE those two, leaving them kLaneShare blocks of the queue (49,152 blocks: 34.0 -> 40.7 GB/s, 131,072: 44.9 -> 48.3).
+constexpr uint32_t kLaneMidBlocks = 26624, kLaneWideBlocks = 98304; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
+constexpr uint32_t kLaneShare = 24576, kLaneShareWide = 32768;     // blocks of the queue the lanes leave to the other parsers (K = 2 / K = 1 regime)
 constexpr uint32_t kLaneMinSmall = 61440;  // LDS-staged blocks: lanes beside the LDS-resident parser from 60 Ki blocks on (64 Ki blocks of text: 28.5 against 25.7 GB/s)
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
@@ -2042,6 +2046,18 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     hipError_t e = grow_workspace(wsp, nblocks, &ws, &cap);
     if (e != hipSuccess) return e;
     uint32_t *counters = ws, *queue = ws + 8, *queue2 = ws + 8 + cap;
+    // what this call launches, noted in the branch that launches it (cw_profile_kernels): names as rocprofv3 prints them; a kernel that
+    // decides on the device whether the queue's length is in its range carries the range
+    char launched[320] = "";
+    auto note = [&](const char *fmt, auto... a) __attribute__((format(printf, 2, 0))) {
+        const size_t used = strlen(launched);
+        if (used && used + 3 < sizeof launched) strcat(launched, " + ");
+        const size_t at = strlen(launched);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wformat-security"
+        snprintf(launched + at, sizeof launched - at, fmt, a...);
+#pragma clang diagnostic pop
+    };
 
     if ((e = hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), stream)) != hipSuccess) return e;
     // CW_LZ4_MODE=scan stops after the scan kernel (queued blocks keep sizes[i] = 0xFFFFFFFF): a profiling knob
@@ -2064,21 +2080,22 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             const size_t g = nspans < 256 * wpc ? nspans : 256 * wpc; // 40 KiB of LDS each -> at most 4 per CU
             hipLaunchKernelGGL(lz4_scan_span_kernel, dim3((unsigned)g), dim3(64), 0, stream, src, n, src_stride, (uint32_t)nspans, dst,
                                dst_stride, sizes, scan_probes(n), queue, counters, lg);
+            note("cw::lz4_scan_span_kernel");
         }
         if (done < nblocks) {
             const size_t rest = nblocks - done;
             const size_t sgrid = rest < 256 * wpc ? rest : 256 * wpc;
             hipLaunchKernelGGL(lz4_scan_stream_kernel, dim3((unsigned)sgrid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
                                dst_stride, sizes, scan_probes(n), queue, counters, done, 3u);
+            note("cw::lz4_scan_stream_kernel");
         }
     } else {
         hipLaunchKernelGGL(lz4_scan_kernel, dim3((unsigned)scan_grid), dim3(64), 0, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, scan_probes(n), queue, counters);
+        note("cw::lz4_scan_kernel");
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const bool span = streamable && n >= kChunk && (n & (n - 1)) == 0 && !(mode && strcmp(mode, "stream") == 0) && nblocks >= (65536u / n ? 65536u / n : 1u);
-    const char *scan_name = !streamable ? "cw::lz4_scan_kernel" : span ? "cw::lz4_scan_span_kernel" : "cw::lz4_scan_stream_kernel";
-    if (mode && strcmp(mode, "scan") == 0) { note_kernels(0, scan_name); return hipSuccess; }
+    if (mode && strcmp(mode, "scan") == 0) { note_kernels(0, launched); return hipSuccess; }
     // parse: queued blocks only; LDS admits 160 KiB / lds workgroups per CU
     // CW_LZ4_PARSE=fp: blocks read from global memory go through the fingerprint parser (20 KiB of LDS, 8 blocks per CU).
     // Measured on text at 64 KiB: 11.9 GB/s against 14.2 GB/s for the second generation with its 10 blocks per CU -- both
@@ -2105,7 +2122,9 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     // blocks 18.3 / 17.4, 24 Ki 18.3 / 20.7; 8 KiB 24 Ki blocks 20.9 / 18.5, 32 Ki 20.4 / 22.7 (on small blocks the wavefront parser
     // is faster and a lane slower per byte: every block starts on an empty table, and has one to zero)
     const uint32_t lane_min = lanes_env ? (uint32_t)atoi(lanes_env)
-                              : staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : n > 16384 ? 14336u : n > 8192 ? 20480u : 28672u;
+                              : staged ? kLaneMinSmall : n > 32768 ? kLaneMidBlocks : n > 16384 ? 40960u : n > 8192 ? 61440u : 98304u;
+    // (16 KiB blocks: the register-table + wavefront parsers 25.7 / 27.9 / 29.3 GB/s at 16 Ki / 32 Ki / 64 Ki blocks against the lanes' 19.5 / 25.0 / 30.1;
+    //  8 KiB blocks: 25.5 / 28.8 / 30.0 at 16 Ki / 48 Ki / 96 Ki blocks against 21.4 / 21.3 / 30.3)
     bool lanes_used = false, lanes_beside = false;
     const char *lf_env = tune("CW_LZ4_LANES_FP"); // profiling knob: 0 = 16-bit table entries without fingerprints for blocks > 4 KiB
     const bool lanes_fp = !(lf_env && lf_env[0] == '0');
@@ -2135,14 +2154,20 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             if (wsp.lane_tabs) { e = hipFree(wsp.lane_tabs); if (e != hipSuccess) return e; }
             wsp.lane_tabs = nullptr; wsp.lane_cap = 0;
             e = hipMalloc(reinterpret_cast<void **>(&wsp.lane_tabs), lgrid * 64 * (size_t)kTabBytes * 2); // (entries of 4 bytes for blocks > 4 KiB)
-            if (e != hipSuccess) return e;
-            wsp.lane_cap = lgrid * 64;
+            if (e != hipSuccess) { // up to 4 GiB: a nearly full device does without the lanes instead of failing the call
+                (void)hipGetLastError();
+                wsp.lane_tabs = nullptr;
+                lgrid = 0;
+            } else {
+                wsp.lane_cap = lgrid * 64;
+            }
         }
+        if (lgrid) {
         // CW_LANES_CONCURRENT=0: one after the other on the caller's stream (the lanes take the whole queue); default: side by side
         const char *cc_env = tune("CW_LANES_CONCURRENT");
         const char *rs_env = tune("CW_LANES_RESERVE");
-        lanes_beside = cc_env ? cc_env[0] != '0' : staged;
-        uint32_t reserve = 0, lmin = lane_min;
+        lanes_beside = cc_env ? cc_env[0] != '0' : true;
+        uint32_t reserve = 0, reserve_wide = 0, lmin = lane_min;
         if (lanes_beside) {
             if (!wsp.side) {
                 if ((e = hipStreamCreateWithFlags(&wsp.side, hipStreamNonBlocking)) != hipSuccess) return e;
@@ -2151,20 +2176,30 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             }
             // what the wavefront parser gets through while a lane parses its last block: 4 KiB text, 1 Mi blocks: 8 Ki..40 Ki 40-43 GB/s, 48 Ki 39.8;
             // 256 Ki blocks: 16 Ki / 28 Ki / 40 Ki 37.4 / 39.0 / 41.0
-            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 32768u : 24576u);
+            // blocks > 4 KiB (round 3; corpus, 64 KiB, lanes alone -> lanes beside the other two, GB/s): two positions per iteration, 32 Ki blocks
+            // 29.4 -> 31.0 (reserve 24 Ki), 48 Ki 34.0 -> 40.7 (16-24 Ki), 64 Ki 37.2 -> 40.6 (32 Ki); one position: 128 Ki 44.9 -> 48.3 (32 Ki), 256 Ki 42.8 -> 46.7
+            reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 32768u : kLaneShare);
+            reserve_wide = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : kLaneShareWide;
             if (lane_min > 1 && lmin < reserve + reserve / 4) lmin = reserve + reserve / 4; // (CW_LZ4_LANES=1 in the tests: no reserve)
-            if (lane_min == 1) reserve = 0;
+            if (lane_min == 1) reserve = reserve_wide = 0;
             if ((e = hipEventRecord(wsp.fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(wsp.side, wsp.fork, 0)) != hipSuccess) return e;
         }
         hipStream_t ls = lanes_beside ? wsp.side : stream;
         const uint32_t no_max = 0xFFFFFFFFu;
-#define CW_RING(K, LO, HI) hipLaunchKernelGGL(lz4_lanes_ring_kernel<K>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, \
-                                              sizes, queue, counters, wsp.lane_tabs, LO, reserve, HI)
+        const char *side_tag = lanes_beside ? " [side stream]" : "";
+#define CW_RING(K, LO, HI) do { \
+            const uint32_t lo_ = (LO), hi_ = (HI); \
+            hipLaunchKernelGGL(lz4_lanes_ring_kernel<K>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue, counters, \
+                               wsp.lane_tabs, lo_, hi_ == no_max && lanes_ring < 0 ? reserve_wide : reserve, hi_); \
+            if (hi_ == no_max) note("cw::lz4_lanes_ring_kernel<" #K "> (queue >= %u)%s", lo_, side_tag); \
+            else note("cw::lz4_lanes_ring_kernel<" #K "> (queue in [%u, %u))%s", lo_, hi_, side_tag); } while (0)
         if (n <= 4096)
+        {
             hipLaunchKernelGGL(lz4_lanes_kernel<kLaneTagged>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
                                counters, wsp.lane_tabs, lmin, reserve);
-        else if (lanes_ring < 0 && lanes_beside) CW_RING(1, lmin, no_max); // (a profiling regime: one launch beside the wavefront parser)
+            note("cw::lz4_lanes_kernel<1> (queue >= %u)%s", lmin, side_tag);
+        }
         else if (lanes_ring < 0) {
             if (lmin < kLaneWideBlocks) CW_RING(2, lmin, kLaneWideBlocks);
             if (nblocks >= kLaneWideBlocks) CW_RING(1, lmin < kLaneWideBlocks ? kLaneWideBlocks : lmin, no_max);
@@ -2174,25 +2209,35 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         else if (lanes_ring == 4) CW_RING(4, lmin, no_max);
         else if (lanes_ring == 8) CW_RING(8, lmin, no_max);
 #undef CW_RING
-        else if (lanes_fp)
+        else if (lanes_fp) {
             hipLaunchKernelGGL(lz4_lanes_kernel<kLaneFp>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
                                counters, wsp.lane_tabs, lmin, reserve);
-        else
+            note("cw::lz4_lanes_kernel<2> (queue >= %u)%s", lmin, side_tag);
+        } else {
             hipLaunchKernelGGL(lz4_lanes_kernel<kLanePlain>, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue,
                                counters, wsp.lane_tabs, lmin, reserve);
+            note("cw::lz4_lanes_kernel<0> (queue >= %u)%s", lmin, side_tag);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         lanes_used = true;
+        }
     }
-    // The register-table parser (lz4_vtab_kernel.hip): 16 more chains per CU than the LDS admits, no table traffic.  CW_LZ4_VTAB: 0 = off,
-    // 1 = on the caller's stream ahead of the wavefront parser (it takes the whole queue), 2 = beside the wavefront parser on a second
-    // stream, both pulling from the queue; CW_VTAB_MIN = queued blocks from which it runs, CW_VTAB_RESERVE = blocks it leaves to the
-    // others, CW_VTAB_WPC = its wavefronts per CU (at most 16).
+    // The register-table parser (lz4_vtab_kernel.hip): 16 more chains per CU than the LDS admits, no table traffic.  It runs BESIDE the
+    // wavefront parser on a second stream, both pulling from the scan's queue, whenever the lanes do not take the whole queue
+    // (text, 64 KiB blocks, wavefront parser alone -> both: 3,233 blocks 11.8 -> 15.7 GB/s, 8 Ki 13.3 -> 21.6, 16 Ki 24.5 against the
+    // lanes' 19.5; beside the lanes in their random-line regime it gains nothing -- they keep the memory system busy and its
+    // candidate fetches wait).  CW_LZ4_VTAB: 0 = off, 1 = on the caller's stream AHEAD of the wavefront parser (it takes the whole
+    // queue: tests), 2 = beside (default); CW_VTAB_MIN / CW_VTAB_MAX = queue lengths between which it runs (checked on the device),
+    // CW_VTAB_RESERVE = blocks it leaves to the others, CW_VTAB_WPC = its wavefronts per CU (at most 16), CW_VTAB_GEN = kernel generation.
     const char *vt_env = tune("CW_LZ4_VTAB");
-    const int vt_mode = vt_env ? atoi(vt_env) : 0;
+    const int vt_mode = vt_env ? atoi(vt_env) : 2;
+    const bool cut_first = mode && strcmp(mode, "cut") == 0; // (CW_LZ4_MODE=cut: the first-generation parser only)
     bool vtab_used = false, vtab_beside = false;
-    if (vt_mode > 0 && !use_fp && n >= 64 && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) == 0) {
-        const char *vm_env = tune("CW_VTAB_MIN"), *vr_env = tune("CW_VTAB_RESERVE"), *vw_env = tune("CW_VTAB_WPC");
+    if (vt_mode > 0 && !use_fp && !cut_first && n >= 64 && nblocks >= 64 && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) == 0) {
+        const char *vm_env = tune("CW_VTAB_MIN"), *vx_env = tune("CW_VTAB_MAX"), *vr_env = tune("CW_VTAB_RESERVE"), *vw_env = tune("CW_VTAB_WPC");
         const uint32_t vmin = vm_env ? (uint32_t)atoi(vm_env) : 1u, vres = vr_env ? (uint32_t)atoi(vr_env) : 0u;
+        // lanes that take the whole queue (blocks > 4 KiB) start at lane_min queued blocks: the register-table parser stays below
+        const uint32_t vmax = vx_env ? (uint32_t)atoi(vx_env) : (lanes_used && !lanes_beside ? lane_min : 0xFFFFFFFFu);
         const unsigned vwpc = vw_env && atoi(vw_env) > 0 ? (unsigned)atoi(vw_env) : 16u;
         hipStream_t vs = stream;
         if (vt_mode == 2) {
@@ -2206,7 +2251,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             vs = wsp.side2;
             vtab_beside = true;
         }
-        if ((e = lz4_vtab_launch(src, n, src_stride, nblocks, dst, dst_stride, sizes, queue, counters, vmin, vres, vwpc, vs)) != hipSuccess) return e;
+        const char *vname = nullptr;
+        if ((e = lz4_vtab_launch(src, n, src_stride, nblocks, dst, dst_stride, sizes, queue, counters, vmin, vmax, vres, vwpc, vs, &vname)) != hipSuccess) return e;
+        if (vmax != 0xFFFFFFFFu) note("%s (queue < %u)%s", vname, vmax, vtab_beside ? " [side stream]" : "");
+        else note("%s%s", vname, vtab_beside ? " [side stream]" : "");
         vtab_used = true;
     }
     const char *pwpc_env = tune("CW_PARSE_WPC"); // parse wavefronts per CU (profiling knob; default: all the LDS admits)
@@ -2219,6 +2267,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const char *redo_env = tune("CW_LZ_FORCE_REDO");
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
     if (!cut_only) {
+        note(staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel<%d>" : "cw::lz4_parse_kernel<false>", headw == 32 || headw == 8 ? headw : 16);
         if (staged)
             hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                                dst_stride, sizes, queue, counters, queue2, force_redo);
@@ -2244,21 +2293,8 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         if ((e = hipEventRecord(wsp.join, wsp.side)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, wsp.join, 0)) != hipSuccess) return e;
     }
-    {
-        static thread_local char names[192];
-        const char *lname = n <= 4096 ? "cw::lz4_lanes_kernel<1>"
-                            : lanes_ring < 0 ? (lanes_beside ? "cw::lz4_lanes_ring_kernel<1>" : nblocks >= kLaneWideBlocks && lane_min < kLaneWideBlocks
-                                                ? "cw::lz4_lanes_ring_kernel<2> or <1> by queue length" : nblocks >= kLaneWideBlocks ? "cw::lz4_lanes_ring_kernel<1>"
-                                                : "cw::lz4_lanes_ring_kernel<2>")
-                            : lanes_ring == 1 ? "cw::lz4_lanes_ring_kernel<1>" : lanes_ring == 2 ? "cw::lz4_lanes_ring_kernel<2>"
-                            : lanes_ring == 4 ? "cw::lz4_lanes_ring_kernel<4>" : lanes_ring == 8 ? "cw::lz4_lanes_ring_kernel<8>"
-                            : lanes_fp ? "cw::lz4_lanes_kernel<2>" : "cw::lz4_lanes_kernel<0>"; // (as rocprofv3 prints the instantiations)
-        snprintf(names, sizeof names, "%s + %s%s%s%s", scan_name, vtab_used ? (vtab_beside ? "cw::lz4_vtab_kernel beside " : "cw::lz4_vtab_kernel, then ") : "",
-                 lanes_used ? lname : "", lanes_used ? (lanes_beside ? " beside " : " (large queues), then ") : "",
-                 cut_only ? (staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>")
-                 : staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel" : "cw::lz4_parse_kernel<false>");
-        note_kernels(0, names);
-    }
+    if (cut_only) note(staged ? "cw::lz4_blocks_kernel<true>" : "cw::lz4_blocks_kernel<false>");
+    note_kernels(0, launched); // (the redo pass below finds an empty list unless the LDS ever applied an exchange's lanes out of order)
     // blocks the exchange-based parser handed back (none, unless the LDS ever applies lanes out of order)
     const uint32_t *q = cut_only ? queue : queue2;
     uint32_t *c = cut_only ? counters : counters + 4;

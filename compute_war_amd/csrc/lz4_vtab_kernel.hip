@@ -171,11 +171,11 @@ __device__ __forceinline__ void copy_run(uint8_t *__restrict__ d, const uint8_t 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(CW_VT_COMPILER_VGPRS)))
 lz4_vtab_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                 uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t min_queued,
-                uint32_t reserve)
+                uint32_t max_queued, uint32_t reserve)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t qcount = __builtin_amdgcn_readfirstlane(counters[1]);
-    if (qcount < min_queued) return; // the launch policy's regime test, on the device: the queue's length is only known here
+    if (qcount < min_queued || qcount >= max_queued) return; // the launch policy's regime test, on the device: the queue's length is only known here
     const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
 
     for (;;) {
@@ -350,16 +350,581 @@ lz4_vtab_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation: a batch of K items per memory round trip, the per-item arithmetic on the vector lanes.
+//
+// The first kernel above is bound by SCALAR instruction issue (one scalar ALU per CU, shared by its four SIMDs): ~210 scalar
+// instructions per sequence on text, 16 wavefronts per CU, 18 GB/s; 4 / 8 / 12 / 16 wavefronts per CU give 9.7 / 14.1 / 16.1 / 18.4 GB/s.
+// Here lane k of the wavefront owns item k of a batch -- after a match: insert(ip-2), re-test(ip), probe(ip+1), probe(ip+2); in a
+// continuing search: K probes -- and does everything that is per item on the VALU, all items at once: the item's position from the
+// skip schedule, its 4 + 8 + 4 bytes (one unaligned load each), its hash, and later the candidate's bytes, the 4-byte test and both
+// extensions.  Only what touches the table stays serial and scalar: item after item in position order, each a read and a write of
+// the indexed register (the writes of items behind the first match are taken back from saved words, in reverse order), ~16 scalar
+// instructions per item.  One candidate round trip per batch instead of one per probe.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kItems = 4;
+struct Saved { uint32_t r, l, w; };
+// entry h <- pos; returns the previous entry and what vt_restore needs to take the write back
+__device__ __forceinline__ uint32_t vt_exchange_s(uint32_t h, uint32_t pos, Saved &sv)
+{
+    const uint32_t r = h >> 7, l = (h >> 1) & 63u, sh = (h & 1u) << 4;
+    uint32_t w;
+    asm volatile("s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\t"
+                 "v_readlane_b32 %0, " CW_VT_BASE ", %2\n\t"
+                 "s_set_gpr_idx_off"
+                 : "=s"(w) : "s"(r), "s"(l) : CW_VT_CLOBBER);
+    const uint32_t nw = (w & ~(0xFFFFu << sh)) | (pos << sh);
+    asm volatile("s_lshl_b64 exec, 1, %2\n\t"
+                 "s_set_gpr_idx_on %0, gpr_idx(DST)\n\t"
+                 "v_mov_b32 " CW_VT_BASE ", %1\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "s_mov_b64 exec, -1"
+                 :: "s"(r), "s"(nw), "s"(l) : CW_VT_CLOBBER);
+    sv.r = r; sv.l = l; sv.w = w;
+    return (w >> sh) & 0xFFFFu;
+}
+__device__ __forceinline__ void vt_restore(const Saved &sv)
+{
+    asm volatile("s_lshl_b64 exec, 1, %2\n\t"
+                 "s_set_gpr_idx_on %0, gpr_idx(DST)\n\t"
+                 "v_mov_b32 " CW_VT_BASE ", %1\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "s_mov_b64 exec, -1"
+                 :: "s"(sv.r), "s"(sv.w), "s"(sv.l) : CW_VT_CLOBBER);
+}
+template <int KLANE>
+__device__ __forceinline__ void put_lane(uint32_t &v, uint32_t s)
+{
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(KLANE));
+}
+__device__ __forceinline__ uint32_t probe_delta(uint32_t k)
+{
+    const uint32_t t = 62 + k, q = t >> 6, r = t & 63;
+    return k ? 1 + q * (32 * (q - 1) + r + 1) : 0;
+}
+struct ItemBytes { uint32_t before, at, a0, a1; }; // [p-4, p), [p, p+4), [p+4, p+8), [p+8, p+12)
+// the 16 bytes around position p of the block at g (p + 12 <= n); positions below 4 have their `before` bytes moved to the top
+__device__ __forceinline__ ItemBytes item_bytes(const uint8_t *g, uint32_t p)
+{
+    ItemBytes b;
+    uint32_t w[3];
+    __builtin_memcpy(w, g + p, 12); // one unaligned global_load_dwordx3
+    const uint32_t pb = p < 4 ? 0u : p - 4;
+    uint32_t bw;
+    __builtin_memcpy(&bw, g + pb, 4);
+    b.before = p < 4 ? bw << ((4u - p) * 8u) : bw; // (p = 0: shift by 32 is never used: nothing lies before position 0)
+    b.at = w[0]; b.a0 = w[1]; b.a1 = w[2];
+    return b;
+}
+} // namespace
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(CW_VT_COMPILER_VGPRS)))
+lz4_vtab2_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                 uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t min_queued,
+                 uint32_t max_queued, uint32_t reserve)
+{
+    constexpr int K = kItems;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t kk = lane < (uint32_t)K ? lane : (uint32_t)K - 1; // lanes beyond the batch repeat its last item (no divergence, same lines)
+    const uint32_t qcount = __builtin_amdgcn_readfirstlane(counters[1]);
+    if (qcount < min_queued || qcount >= max_queued) return;
+    const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
+
+    for (;;) {
+        uint32_t qi = qcount;
+        if (lane == 0 && (!reserve || __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + reserve < qcount))
+            qi = atomicAdd(&counters[0], 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (qi >= qcount) break;
+        const size_t blk = queue[qi];
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+        vt_zero();
+
+        uint32_t anchor = 0, op = 0;
+        uint32_t pend_val = 0, pend_pos = 0, pend_cnt = 0; // literals on their way from memory, stored one sequence later
+
+        if (n >= kMFLimit + 1) {
+            // a batch: head (after a match at s): lane 0 inserts s - 2, lane 1 re-tests s, lanes 2.. are probes 0.. of the search that
+            // starts at ip0 = s + 1; otherwise lanes 0.. are probes i0.. of the search that started at ip0
+            bool head = false;
+            uint32_t s = 0, ip0 = 1, i0 = 0;
+            for (;;) {
+                // ---- per lane: position, liveness, bytes, hash ----
+                const uint32_t shift = head ? 2u : 0u;
+                const uint32_t pi = i0 + kk - shift;                       // probe index of this lane (lanes below `shift`: not a probe)
+                uint32_t pos, nxt;
+                if (i0 + (uint32_t)K < 64u) { pos = ip0 + pi; nxt = pos + 1; }    // the first 65 probes of a search are consecutive
+                else { pos = ip0 + probe_delta(pi); nxt = ip0 + probe_delta(pi + 1); }
+                bool live = nxt <= mflimit + 1;                             // the parser stops before a probe whose successor passes the limit
+                if (kk < shift) { pos = kk == 0 ? s - 2 : s; live = true; }
+                const uint32_t nlive = ctz64(~__ballot(live) | (1ull << K));
+                const uint32_t safe = live ? pos : 0u;                      // dead lanes read the block's start (their results are never used)
+                const ItemBytes pb = item_bytes(g, safe);
+                const uint32_t h = (pb.at * 2654435761u) >> 19;
+
+                // ---- table, item after item ----
+                uint32_t cand = 0;
+                Saved sv[K];
+#define CW_VT_ITEM(I)                                                                                              \
+                if ((uint32_t)(I) < nlive) {                                                                                \
+                    const uint32_t old_ = vt_exchange_s(__builtin_amdgcn_readlane(h, I), __builtin_amdgcn_readlane(pos, I), sv[I]); \
+                    put_lane<I>(cand, old_);                                                                                \
+                }
+                CW_VT_ITEM(0) CW_VT_ITEM(1) CW_VT_ITEM(2) CW_VT_ITEM(3)
+#undef CW_VT_ITEM
+                static_assert(K == 4, "the item list above is written out for four items");
+
+                // ---- candidates: bytes, the 4-byte test, both extensions (per lane) ----
+                const bool tested = kk < nlive && kk >= (head ? 1u : 0u); // (lane 0 of a head batch only inserts)
+                ItemBytes cb = item_bytes(g, tested ? cand : 0u);
+                asm volatile("" : "+v"(cb.before), "+v"(cb.at)); // both loads in flight before the test (hipcc would sink the second one behind it)
+                const unsigned long long hits = __ballot(tested && cb.at == pb.at) & ((1ull << K) - 1);
+                if (!hits) {
+                    if (nlive < (uint32_t)K) break;                        // the search ran into the end of the block: last literals
+                    i0 += (uint32_t)K - shift;
+                    head = false;
+                    continue;
+                }
+                const uint32_t j = (uint32_t)__builtin_ctzll(hits);
+                // take back the writes of the items behind the match, last first
+                if (3 > j && 3 < nlive) vt_restore(sv[3]);
+                if (2 > j && 2 < nlive) vt_restore(sv[2]);
+                if (1 > j && 1 < nlive) vt_restore(sv[1]);
+                // forward: bytes 4..11 of the match; backward: up to 4 bytes
+                uint32_t fwd, bck;
+                {
+                    const uint32_t x0 = pb.a0 ^ cb.a0, x1 = pb.a1 ^ cb.a1;
+                    const uint32_t f = x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;
+                    const uint32_t y = pb.before ^ cb.before;
+                    const uint32_t b = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+                    const uint32_t packed = __builtin_amdgcn_readlane(f | (b << 8), j);
+                    fwd = packed & 0xFFu; bck = packed >> 8;
+                }
+                const uint32_t cur = __builtin_amdgcn_readlane(pos, j), match = __builtin_amdgcn_readlane(cand, j);
+                uint32_t back = 0;
+                if (!(head && j == 1)) { // (a re-test hit takes no literals back: the parser jumps straight to the match)
+                    const uint32_t room = cur - anchor < match ? cur - anchor : match;
+                    back = bck < room ? bck : room;
+                    if (bck == 4 && room > 4) {
+                        for (;;) {
+                            const uint32_t jj = back + lane + 1;
+                            const bool ok = jj <= room && g[cur - jj] == g[match - jj];
+                            const uint32_t cnt = ctz64(~__ballot(ok));
+                            back += cnt;
+                            if (cnt < 64) break;
+                        }
+                    }
+                }
+                uint32_t mc = fwd;
+                {
+                    const uint32_t lim = matchlimit - (cur + kMinMatch);
+                    if (mc == 8 && lim > 8) {
+                        for (;;) {
+                            const uint32_t i = cur + kMinMatch + mc + lane;
+                            const bool ok = i < matchlimit && g[i] == g[match + kMinMatch + mc + lane];
+                            const uint32_t cnt = ctz64(~__ballot(ok));
+                            mc += cnt;
+                            if (cnt < 64) break;
+                        }
+                    }
+                    if (mc > lim) mc = lim;
+                }
+                const uint32_t mend = cur + kMinMatch + mc; // first byte after the match
+                const uint32_t off = cur - match;
+                const uint32_t lit = cur - back - anchor;
+                mc += back;
+
+                // ---- emit: token, literals [anchor, anchor + lit), offset, match length ----
+                if (pend_cnt) {
+                    if (lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
+                    pend_cnt = 0;
+                }
+                const uint32_t tok_pos = op;
+                uint32_t token;
+                op += 1;
+                if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
+                else token = lit << 4;
+                if (lit) {
+                    if (lit <= 64) {
+                        pend_val = lane < lit ? g[anchor + lane] : 0u;
+                        pend_pos = op; pend_cnt = lit;
+                    } else {
+                        copy_run(out + op, g + anchor, lit, lane);
+                    }
+                    op += lit;
+                }
+                const uint32_t off_pos = op;
+                op += 2;
+                if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
+                else token += mc;
+                if (lane < 3) {
+                    const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
+                    const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
+                    out[where] = (uint8_t)what;
+                }
+                anchor = mend;
+                if (mend > mflimit) break; // end of parse: the remaining bytes are literals
+                head = true; s = mend; ip0 = mend + 1; i0 = 0;
+            }
+        }
+        if (pend_cnt && lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
+
+        // ---- last literals ----
+        {
+            const uint32_t run = n - anchor;
+            const uint32_t tok_pos = op;
+            op += 1;
+            if (run >= 15) {
+                if (lane == 0) out[tok_pos] = 15u << 4;
+                op += put_len(out + op, run - 15, lane);
+            } else if (lane == 0) {
+                out[tok_pos] = (uint8_t)(run << 4);
+            }
+            copy_run(out + op, g + anchor, run, lane);
+            op += run;
+        }
+        if (lane == 0) sizes[blk] = op;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Third generation: the first kernel's serial chain (scalar loads through the scalar cache: the lowest latency the chip offers, and
+// one candidate round trip per probe as the parser needs it), with the scalar unit relieved.  The first kernel issues ~210 scalar
+// instructions per sequence and is bound by that (16 wavefronts share one scalar ALU per CU); the vector ALUs are idle.  Here
+//   * the half-word arithmetic of a table operation (extract the old entry, merge the new one into its 32-bit word) runs on the VALU
+//     on wave-uniform operands, inside one block of inline assembly with the two indexed register accesses;
+//   * windows are loaded from the position's own dword (no bytes in front of it, so no special case for positions below 4); the
+//     bytes in front are fetched only when a match may actually move back (literals pending and candidate > 0);
+//   * consecutive probes re-use the window in registers (a new one is loaded when the position crosses a dword);
+//   * both extensions, the token and all output addresses are computed on the VALU in wave-uniform VGPRs (anchor and output
+//     position live there); the scalar unit keeps what only it can do: scalar loads and their addresses, the hash (one s_mul),
+//     register indices, EXEC masks and branches.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// entry h <- pos; returns the previous entry.  k_ffff: a VGPR holding 0xFFFF in every lane.
+__device__ __forceinline__ uint32_t vt3_exchange(uint32_t h, uint32_t pos, uint32_t k_ffff)
+{
+    const uint32_t r = h >> 7, l = (h >> 1) & 63u;
+    uint32_t old, w, t, ps, m, nw;
+    asm volatile("s_set_gpr_idx_on %[r], gpr_idx(SRC0)\n\t"
+                 "v_readlane_b32 %[w], " CW_VT_BASE ", %[l]\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "v_and_b32 %[t], 1, %[h]\n\t"
+                 "v_lshlrev_b32 %[t], 4, %[t]\n\t"             // 0 or 16: the half of the word
+                 "v_lshlrev_b32_e64 %[ps], %[t], %[pos]\n\t"
+                 "v_lshlrev_b32 %[m], %[t], %[kf]\n\t"
+                 "v_bfi_b32 %[nw], %[m], %[ps], %[w]\n\t"      // (mask & pos << sh) | (~mask & word)
+                 "v_lshrrev_b32_e64 %[t], %[t], %[w]\n\t"
+                 "s_lshl_b64 exec, 1, %[l]\n\t"
+                 "s_set_gpr_idx_on %[r], gpr_idx(DST)\n\t"
+                 "v_mov_b32 " CW_VT_BASE ", %[nw]\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_readfirstlane_b32 %[old], %[t]\n\t"
+                 "s_and_b32 %[old], %[old], 0xffff"
+                 : [old] "=s"(old), [w] "=&s"(w), [t] "=&v"(t), [ps] "=&v"(ps), [m] "=&v"(m), [nw] "=&v"(nw)
+                 : [r] "s"(r), [l] "s"(l), [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
+                 : "scc", CW_VT_CLOBBER);
+    return old;
+}
+// entry h <- pos (the previous entry is of no interest: the insert in front of a re-test)
+__device__ __forceinline__ void vt3_put(uint32_t h, uint32_t pos, uint32_t k_ffff)
+{
+    const uint32_t r = h >> 7, l = (h >> 1) & 63u;
+    uint32_t w, t, ps, m, nw;
+    asm volatile("s_set_gpr_idx_on %[r], gpr_idx(SRC0)\n\t"
+                 "v_readlane_b32 %[w], " CW_VT_BASE ", %[l]\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "v_and_b32 %[t], 1, %[h]\n\t"
+                 "v_lshlrev_b32 %[t], 4, %[t]\n\t"
+                 "v_lshlrev_b32_e64 %[ps], %[t], %[pos]\n\t"
+                 "v_lshlrev_b32 %[m], %[t], %[kf]\n\t"
+                 "v_bfi_b32 %[nw], %[m], %[ps], %[w]\n\t"
+                 "s_lshl_b64 exec, 1, %[l]\n\t"
+                 "s_set_gpr_idx_on %[r], gpr_idx(DST)\n\t"
+                 "v_mov_b32 " CW_VT_BASE ", %[nw]\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [w] "=&s"(w), [t] "=&v"(t), [ps] "=&v"(ps), [m] "=&v"(m), [nw] "=&v"(nw)
+                 : [r] "s"(r), [l] "s"(l), [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
+                 : "scc", CW_VT_CLOBBER);
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 sc_load8(const u32x4 &rs, uint32_t off)
+{
+    u32x2 v;
+    asm volatile("s_buffer_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(rs), "s"(off));
+    return v;
+}
+__device__ __forceinline__ uint32_t sc_load4(const u32x4 &rs, uint32_t off)
+{
+    uint32_t v;
+    asm volatile("s_buffer_load_dword %0, %1, %2" : "=s"(v) : "s"(rs), "s"(off));
+    return v;
+}
+__device__ __forceinline__ void sc_wait3(u32x8 &a, u32x8 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+__device__ __forceinline__ void sc_wait3(u32x8 &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+__device__ __forceinline__ void sc_wait3(u32x8 &a, u32x2 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+__device__ __forceinline__ void sc_wait3(uint32_t &a, uint32_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+// a wave-uniform value moved to a vector register: what is computed from it runs on the VALU
+__device__ __forceinline__ uint32_t to_v(uint32_t s)
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+// 4 bytes at bit offset sh (0, 8, 16 or 24) of the 8 bytes lo | hi << 32, on the scalar unit (lo, hi: an aligned register pair)
+__device__ __forceinline__ uint32_t cut32(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
+// 8 bytes at bit offset sh of the 12 bytes d1 | d2 << 32 | d3 << 64, on the VALU (wave-uniform vector registers)
+__device__ __forceinline__ void cut64_v(uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sh, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t v1 = to_v(d1), v2 = to_v(d2), v3 = to_v(d3);
+    lo = __builtin_amdgcn_alignbit(v2, v1, sh);
+    hi = __builtin_amdgcn_alignbit(v3, v2, sh);
+}
+// number of equal low bytes of two 8-byte values (0..8), on the VALU
+__device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi)
+{
+    const uint32_t x0 = alo ^ blo, x1 = ahi ^ bhi;
+    return x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;
+}
+} // namespace
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(CW_VT_COMPILER_VGPRS)))
+lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                 uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t min_queued,
+                 uint32_t max_queued, uint32_t reserve)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qcount = __builtin_amdgcn_readfirstlane(counters[1]);
+    if (qcount < min_queued || qcount >= max_queued) return;
+    const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
+    const uint32_t k_ffff = to_v(0xFFFFu);
+
+    for (;;) {
+        uint32_t qi = qcount;
+        if (lane == 0 && (!reserve || __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + reserve < qcount))
+            qi = atomicAdd(&counters[0], 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (qi >= qcount) break;
+        const size_t blk = queue[qi];
+        const uint8_t *g = src + blk * src_stride;
+        uint8_t *out = dst + blk * dst_stride;
+        u32x4 rs;
+        {
+            const uint64_t a = reinterpret_cast<uint64_t>(g);
+            rs.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
+            rs.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xFFFFu);
+            rs.z = n;
+            rs.w = 0x00020000u;
+        }
+        vt_zero();
+
+        // wave-uniform state in vector registers: anchor, output position; a pending literal copy (per lane: the byte)
+        uint32_t anchor = to_v(0), op = to_v(0);
+        uint32_t pend_val = 0, pend_pos = to_v(0);
+        uint32_t pend_cnt = 0; // scalar
+
+        if (n >= kMFLimit + 1) {
+            // scalar state of the search: the probe position cur, its window wp = the 32 bytes from pb4 = cur & ~3 on
+            uint32_t cur = 1, pb4 = 0;
+            u32x8 wp = sc_load32(rs, 0);
+            sc_wait3(wp);
+            // one probe: the table exchange, then the candidate's window and the next position's window in ONE round trip
+#define CW_VT3_PROBE(FIP)                                                                                                      \
+            const uint32_t psh = (cur - pb4) * 8u;                                                                             \
+            const uint32_t v = cut32(wp[0], wp[1], psh);                                                                       \
+            const uint32_t cand = vt3_exchange((v * 2654435761u) >> 19, cur, k_ffff);                                          \
+            const uint32_t cb4 = cand & ~3u, csh = (cand & 3u) * 8u, fb4 = (FIP) & ~3u;                                         \
+            u32x8 wc, wq;                                                                                                      \
+            asm volatile("s_buffer_load_dwordx8 %0, %2, %3\n\ts_buffer_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"      \
+                         : "=&s"(wc), "=&s"(wq) : "s"(rs), "s"(cb4), "s"(fb4));                                                \
+            const bool hit = cut32(wc[0], wc[1], csh) == v;
+#define CW_VT3_ADVANCE(FIP)                                                                                                    \
+            if (fb4 != pb4) { wp = wq; pb4 = fb4; }                                                                            \
+            cur = (FIP);
+
+            for (;;) { // one sequence per iteration
+                // ---- search: probe cur, then positions with a stride that grows every 64 misses ----
+                uint32_t mcur = 0, mcand = 0, mpsh = 0, mcsh = 0, mcb4 = 0;
+                u32x8 mwc;
+                bool found = false;
+                {
+                    uint32_t step = 1, nb = 64;
+                    for (;;) {
+                        const uint32_t fip = cur + step;
+                        step = nb++ >> 6;
+                        if (fip > mflimit + 1) break;
+                        CW_VT3_PROBE(fip)
+                        if (hit) { found = true; mcur = cur; mcand = cand; mpsh = psh; mcsh = csh; mcb4 = cb4; mwc = wc; break; }
+                        CW_VT3_ADVANCE(fip)
+                    }
+                }
+                if (!found) break; // -> last literals
+                bool first = true; // the match came out of the search (it may move back); false: out of the re-test after a match
+                for (;;) { // next_match
+                    const uint32_t vcur = to_v(mcur), vcand = to_v(mcand);
+                    uint32_t back = to_v(0);
+                    if (first) {
+                        // bytes the match may move back over: pending literals, and the candidate must stay >= 0
+                        const uint32_t room = min(vcur - anchor, vcand);
+                        if (__builtin_amdgcn_readfirstlane(room) != 0) {
+                            // the 4 bytes in front of both positions (an offset below zero reads as zero; room < 4 then anyway)
+                            uint32_t fp = sc_load4(rs, pb4 - 4u), fc = sc_load4(rs, mcb4 - 4u);
+                            sc_wait3(fp, fc);
+                            const uint32_t bp = __builtin_amdgcn_alignbit(to_v(wp[0]), to_v(fp), mpsh);
+                            const uint32_t bc = __builtin_amdgcn_alignbit(to_v(mwc[0]), to_v(fc), mcsh);
+                            const uint32_t y = bp ^ bc;
+                            const uint32_t b = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
+                            back = min(b, room);
+                            if (__builtin_amdgcn_readfirstlane((uint32_t)(b == 4 && room > 4))) { // rare: more than 4 bytes
+                                uint32_t bk = 4;
+                                const uint32_t rm = __builtin_amdgcn_readfirstlane(room);
+                                for (;;) {
+                                    const uint32_t jj = bk + lane + 1;
+                                    const bool ok = jj <= rm && g[mcur - jj] == g[mcand - jj];
+                                    const uint32_t cnt = ctz64(~__ballot(ok));
+                                    bk += cnt;
+                                    if (cnt < 64) break;
+                                }
+                                back = to_v(bk);
+                            }
+                        }
+                    }
+                    // forward: bytes 4..11 behind both positions, then 12..19, then the byte loop
+                    uint32_t mc;
+                    {
+                        uint32_t plo, phi, clo, chi;
+                        cut64_v(wp[1], wp[2], wp[3], mpsh, plo, phi);
+                        cut64_v(mwc[1], mwc[2], mwc[3], mcsh, clo, chi);
+                        mc = equal_bytes_v(plo, phi, clo, chi);
+                        const uint32_t lim = to_v(matchlimit - kMinMatch) - vcur;
+                        if (__builtin_amdgcn_readfirstlane((uint32_t)(mc == 8 && lim > 8))) {
+                            cut64_v(wp[3], wp[4], wp[5], mpsh, plo, phi);
+                            cut64_v(mwc[3], mwc[4], mwc[5], mcsh, clo, chi);
+                            mc = 8u + equal_bytes_v(plo, phi, clo, chi);
+                            if (__builtin_amdgcn_readfirstlane((uint32_t)(mc == 16 && lim > 16))) {
+                                uint32_t m2 = 16;
+                                for (;;) {
+                                    const uint32_t i = mcur + kMinMatch + m2 + lane;
+                                    const bool ok = i < matchlimit && g[i] == g[mcand + kMinMatch + m2 + lane];
+                                    const uint32_t cnt = ctz64(~__ballot(ok));
+                                    m2 += cnt;
+                                    if (cnt < 64) break;
+                                }
+                                mc = to_v(m2);
+                            }
+                        }
+                        mc = min(mc, lim);
+                    }
+                    const uint32_t vmend = vcur + kMinMatch + mc;     // first byte after the match
+                    const uint32_t mend = __builtin_amdgcn_readfirstlane(vmend);
+                    const bool more = mend <= mflimit;
+                    // the windows of what follows the match, now: the emission below does not wait for them
+                    u32x8 wnext;
+                    u32x2 wins;
+                    const uint32_t nb4 = mend & ~3u, ib4 = (mend - 2u) & ~3u;
+                    if (more) { wnext = sc_load32(rs, nb4); wins = sc_load8(rs, ib4); }
+
+                    // ---- emit (VALU): token, literals [anchor, anchor + lit), offset, match length ----
+                    const uint32_t lit = vcur - back - anchor;
+                    const uint32_t off = vcur - vcand;
+                    const uint32_t mlen = mc + back;
+                    if (pend_cnt) { // the previous sequence's literals (loaded a sequence ago)
+                        if (lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
+                        pend_cnt = 0;
+                    }
+                    const uint32_t tok_pos = op;
+                    const uint32_t token = (min(lit, 15u) << 4) | min(mlen, 15u);
+                    op += 1;
+                    const uint32_t slit = __builtin_amdgcn_readfirstlane(lit);
+                    if (slit) {
+                        if (slit >= 15) op += put_len(out + __builtin_amdgcn_readfirstlane(op), slit - 15, lane);
+                        if (slit <= 64) {
+                            pend_val = lane < slit ? g[__builtin_amdgcn_readfirstlane(anchor) + lane] : 0u;
+                            pend_pos = op; pend_cnt = slit;
+                        } else {
+                            copy_run(out + __builtin_amdgcn_readfirstlane(op), g + __builtin_amdgcn_readfirstlane(anchor), slit, lane);
+                        }
+                        op += lit;
+                    }
+                    const uint32_t off_pos = op;
+                    op += 2;
+                    if (__builtin_amdgcn_readfirstlane((uint32_t)(mlen >= 15)))
+                        op += put_len(out + __builtin_amdgcn_readfirstlane(op), __builtin_amdgcn_readfirstlane(mlen) - 15, lane);
+                    if (lane < 3) { // token and the two offset bytes: three lanes, one store instruction
+                        const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
+                        const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
+                        out[where] = (uint8_t)what;
+                    }
+                    anchor = vmend;
+                    if (!more) { cur = mend; break; }
+
+                    // ---- table: insert mend - 2, then the immediate re-test at mend ----
+                    sc_wait3(wnext, wins);
+                    vt3_put((cut32(wins[0], wins[1], ((mend - 2u) & 3u) * 8u) * 2654435761u) >> 19, mend - 2u, k_ffff);
+                    wp = wnext; pb4 = nb4; cur = mend;
+                    {
+                        const uint32_t fip = cur + 1;
+                        CW_VT3_PROBE(fip)
+                        if (hit) { first = false; mcur = cur; mcand = cand; mpsh = psh; mcsh = csh; mcb4 = cb4; mwc = wc; continue; }
+                        CW_VT3_ADVANCE(fip)
+                    }
+                    break;
+                }
+                if (cur > mflimit) break; // (cur = mend past the limit: the remaining bytes are literals)
+            }
+#undef CW_VT3_PROBE
+#undef CW_VT3_ADVANCE
+        }
+        const uint32_t s_anchor = __builtin_amdgcn_readfirstlane(anchor);
+        uint32_t s_op = __builtin_amdgcn_readfirstlane(op);
+        if (pend_cnt && lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
+
+        // ---- last literals ----
+        {
+            const uint32_t run = n - s_anchor;
+            const uint32_t tok_pos = s_op;
+            s_op += 1;
+            if (run >= 15) {
+                if (lane == 0) out[tok_pos] = 15u << 4;
+                s_op += put_len(out + s_op, run - 15, lane);
+            } else if (lane == 0) {
+                out[tok_pos] = (uint8_t)(run << 4);
+            }
+            copy_run(out + s_op, g + s_anchor, run, lane);
+            s_op += run;
+        }
+        if (lane == 0) sizes[blk] = s_op;
+    }
+}
+
 // grid: as many single-wavefront workgroups as the register file admits (128 VGPRs -> 4 per SIMD, 16 per CU), at most one per queued block
 hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *dst, size_t dst_stride, uint32_t *sizes,
-                           const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t reserve, unsigned waves_per_cu, hipStream_t stream)
+                           const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t max_queued, uint32_t reserve,
+                           unsigned waves_per_cu, hipStream_t stream, const char **kernel_name)
 {
+    // CW_VTAB_GEN: 1 = the all-scalar kernel, 2 = batches of four items, 3 = the scalar chain with the VALU's help.  Default by measurement
+    // (GB/s alone, 16 wavefronts per CU): text, 64 KiB blocks, 8 Ki blocks 18.4 (1) / 13.7 (2) / 20.8 (3), 3,233 blocks 13.6 / 11.3 / 17.1;
+    // corpus, 4 KiB blocks 15.4-16.0 (1) against 17.8-17.9 (2)
+    const char *gen_env = tune("CW_VTAB_GEN");
+    const int gen = gen_env ? atoi(gen_env) : n <= 4096 ? 2 : 3;
     if ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) return hipErrorInvalidValue; // the scalar loads are dword loads
     size_t grid = 256 * (size_t)(waves_per_cu ? waves_per_cu : 16);
     if (grid > nblocks) grid = nblocks;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(lz4_vtab_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
-                       min_queued, reserve);
+    if (kernel_name) *kernel_name = gen == 3 ? "cw::lz4_vtab3_kernel" : gen == 1 ? "cw::lz4_vtab_kernel" : "cw::lz4_vtab2_kernel";
+    if (gen == 3)
+        hipLaunchKernelGGL(lz4_vtab3_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
+                           min_queued, max_queued, reserve);
+    else if (gen == 1)
+        hipLaunchKernelGGL(lz4_vtab_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
+                           min_queued, max_queued, reserve);
+    else
+        hipLaunchKernelGGL(lz4_vtab2_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
+                           min_queued, max_queued, reserve);
     return hipGetLastError();
 }
 

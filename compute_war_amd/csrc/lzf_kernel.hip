@@ -1070,6 +1070,13 @@ void lzf_release_workspaces()
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {
+    // what this call launches, noted where it is launched (cw_profile_kernels); names as rocprofv3 prints them
+    char launched[320] = "";
+    auto note = [&](const char *name) {
+        if (strstr(launched, name)) return; // (rounds repeat their kernels)
+        const size_t used = strlen(launched);
+        if (used + strlen(name) + 4 < sizeof launched) { if (used) strcat(launched, " + "); strcat(launched, name); }
+    };
     if (nblocks == 0) return hipSuccess;
     if (block_bytes == 0 || block_bytes > 65536) return hipErrorInvalidValue;
     const uint32_t n = (uint32_t)block_bytes;
@@ -1105,8 +1112,8 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         // (blocks of 4-8 KiB: the chain kernels win up to ~18 Ki blocks -- text, 8 KiB, 16 Ki blocks 11.0 against 10.6 GB/s, 24 Ki 11.3 / 13.0)
         const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? (n > 8192 ? kLzfLaneMinBlocks : 18432u) : kLzfLaneMinSmall);
         const char *cc_env = tune("CW_LANES_CONCURRENT");
-        const bool use_lanes = lane_min && nblocks >= lane_min;
-        const bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
+        bool use_lanes = lane_min && nblocks >= lane_min;
+        bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
         const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? kLzfBesideRound : ws_bytes / (2 * (size_t)n2);
         const size_t chunk_max = chunk_cap < ws_bytes / (2 * (size_t)n2) ? chunk_cap : ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
@@ -1138,10 +1145,11 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             }
             if (!w.counter && (e = hipMalloc(reinterpret_cast<void **>(&w.counter), kCtrBytes)) != hipSuccess) return e;
         }
+        size_t lgrid = 0; // workgroups of the lane-per-block kernel
         if (use_lanes) {
             const char *lw_env = tune("CW_LANES_WPC");
             const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 4;
-            size_t lgrid = (nblocks + 63) / 64;
+            lgrid = (nblocks + 63) / 64;
             if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
             const char *rs0_env = tune("CW_LANES_RESERVE");
             const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
@@ -1151,9 +1159,17 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 if (w.lane_tabs) { e = hipFree(w.lane_tabs); if (e != hipSuccess) return e; }
                 w.lane_tabs = nullptr; w.lane_cap = 0;
                 e = hipMalloc(reinterpret_cast<void **>(&w.lane_tabs), lgrid * 64 * (size_t)kLzfTabBytes);
-                if (e != hipSuccess) return e;
-                w.lane_cap = lgrid * 64;
+                if (e != hipSuccess) { // up to 8 GiB: a nearly full device does without the lanes instead of failing the call
+                    (void)hipGetLastError();
+                    w.lane_tabs = nullptr;
+                    use_lanes = beside = false;
+                } else {
+                    w.lane_cap = lgrid * 64;
+                }
             }
+        }
+        if (use_lanes) {
+            LinkSpace &w = entry->s;
             if (w.hb_cap < nblocks) { // a block is handed back once at most
                 if (w.handback) { e = hipFree(w.handback); if (e != hipSuccess) return e; }
                 w.handback = nullptr; w.hb_cap = 0;
@@ -1177,11 +1193,13 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 lstream = w.side;
             }
             if (n <= 4096)
+                { note(beside ? "cw::lzf_lanes_kernel<true> [side stream]" : "cw::lzf_lanes_kernel<true>");
                 hipLaunchKernelGGL(lzf_lanes_kernel<true>, dim3((unsigned)lgrid), dim3(64), 0, lstream, src, n, src_stride, nblocks, dst, dst_stride,
-                                   sizes, w.lane_tabs, w.counter, lane_reserve, w.handback);
+                                   sizes, w.lane_tabs, w.counter, lane_reserve, w.handback); }
             else
+                { note(beside ? "cw::lzf_lanes_kernel<false> [side stream]" : "cw::lzf_lanes_kernel<false>");
                 hipLaunchKernelGGL(lzf_lanes_kernel<false>, dim3((unsigned)lgrid), dim3(64), 0, lstream, src, n, src_stride, nblocks, dst, dst_stride,
-                                   sizes, w.lane_tabs, w.counter, lane_reserve, w.handback);
+                                   sizes, w.lane_tabs, w.counter, lane_reserve, w.handback); }
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         ls = entry->s;
@@ -1208,6 +1226,8 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             const LaneShare share = {beside && !listed ? ls.counter : nullptr, first, nblocks, (uint32_t)(first / chunk + 1), spin_cap};
             const BlockList list = {listed ? ls.handback : nullptr, listed ? ls.counter + kCtrHanded : nullptr, (uint32_t)first};
             const size_t off = listed ? 0 : first; // listed blocks are addressed through the list, from the batch's base
+            note(listed ? "cw::lzf_links_kernel (handed-back blocks)" : "cw::lzf_links_kernel");
+            note(big ? "cw::lzf_chain_kernel<true>" : "cw::lzf_chain_kernel<false>");
             hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, src + off * src_stride, n,
                                src_stride, nb, ls.p, n2, sizes + off, force_redo, share, list);
             const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
@@ -1239,28 +1259,25 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                 if ((e = round(first, nblocks - first < hb_chunk ? nblocks - first : hb_chunk, true)) != hipSuccess) return e;
         hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                            dst_stride, sizes, in_lds, 1u, beside ? ls.counter + kCtrFailed : nullptr);
-        note_kernels(0, beside ? (big ? "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<true>"
-                                      : n <= 4096 ? "cw::lzf_lanes_kernel<true> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>"
-                                                  : "cw::lzf_lanes_kernel<false> beside cw::lzf_links_kernel + cw::lzf_chain_kernel<false>")
-                               : use_lanes ? (n <= 4096 ? "cw::lzf_lanes_kernel<true>, then cw::lzf_links_kernel + cw::lzf_chain_kernel<false> on what it passed on"
-                                              : big ? "cw::lzf_lanes_kernel<false>, then cw::lzf_links_kernel + cw::lzf_chain_kernel<true> on what it passed on"
-                                                    : "cw::lzf_lanes_kernel<false>, then cw::lzf_links_kernel + cw::lzf_chain_kernel<false> on what it passed on")
-                               : big ? "cw::lzf_links_kernel + cw::lzf_chain_kernel<true>" : "cw::lzf_links_kernel + cw::lzf_chain_kernel<false>");
+        note_kernels(0, launched);
         return hipGetLastError();
     }
     if (!cut_only) {
         if (in_lds)
+            { note("cw::lzf_parse_kernel<true>");
             hipLaunchKernelGGL(lzf_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                               dst_stride, sizes, force_redo);
+                               dst_stride, sizes, force_redo); }
         else
+            { note("cw::lzf_parse_kernel<false>");
             hipLaunchKernelGGL(lzf_parse_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
-                               dst_stride, sizes, force_redo);
+                               dst_stride, sizes, force_redo); }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(lzf_blocks_kernel, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                        dst_stride, sizes, in_lds, cut_only ? 0u : 1u, static_cast<const uint32_t *>(nullptr));
-    note_kernels(0, cut_only ? "cw::lzf_blocks_kernel" : in_lds ? "cw::lzf_parse_kernel<true>" : "cw::lzf_parse_kernel<false>");
+    if (cut_only) note("cw::lzf_blocks_kernel");
+    note_kernels(0, launched);
     return hipGetLastError();
 }
 

@@ -651,10 +651,13 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
     const dim3 grid((unsigned)((nblocks + CW_SKEIN_THREADS - 1) / CW_SKEIN_THREADS)), block(CW_SKEIN_THREADS);
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | src_stride) & 15) == 0;
     const bool ragged = block_bytes == 0 || (block_bytes % (NW * 8)) != 0;
-#define CW_LAUNCH(A, R) hipLaunchKernelGGL((skein_blocks_kernel<NW, A, R>), grid, block, 0, stream, \
-                                           src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
-#define CW_LAUNCH_LINES(A) hipLaunchKernelGGL((skein_lines_kernel<NW, A>), grid, block, 0, stream, \
-                                              src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes)
+    // the name is noted by the macro that launches (cw_profile_kernels), spelled as rocprofv3 prints the instantiation
+#define CW_LAUNCH(A, R) do { hipLaunchKernelGGL((skein_blocks_kernel<NW, A, R>), grid, block, 0, stream, \
+                                                src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes); \
+                             note_kernels(1, NW == 8 ? "cw::skein_blocks_kernel<8, " #A ", " #R ">" : "cw::skein_blocks_kernel<4, " #A ", " #R ">"); } while (0)
+#define CW_LAUNCH_LINES(A) do { hipLaunchKernelGGL((skein_lines_kernel<NW, A>), grid, block, 0, stream, \
+                                                   src, block_bytes, src_stride, nblocks, iv, digests, digest_bytes); \
+                                note_kernels(1, NW == 8 ? "cw::skein_lines_kernel<8, " #A ">" : "cw::skein_lines_kernel<4, " #A ">"); } while (0)
     // Two hot kernels for aligned, whole-step blocks: the line kernel (105 VGPRs, every cache line fetched once) and
     // the step kernel (92 VGPRs, 64 bytes per step, ~40 % of the lines fetched twice).  Alone they are equally fast;
     // beside codec wavefronts the step kernel keeps 4 instead of 3 hash wavefronts per SIMD, which helped at 512 Ki
@@ -667,8 +670,6 @@ static hipError_t launch_skein(const uint8_t *src, size_t block_bytes, size_t sr
     else if (aligned) CW_LAUNCH(true, true);
     else if (!ragged) CW_LAUNCH_LINES(false);
     else CW_LAUNCH(false, true);
-    note_kernels(1, NW == 8 ? (!ragged && !(aligned && steps) ? (aligned ? "cw::skein_lines_kernel<8, true>" : "cw::skein_lines_kernel<8, false>") : "cw::skein_blocks_kernel<8, ...>")
-                            : (!ragged && !(aligned && steps) ? (aligned ? "cw::skein_lines_kernel<4, true>" : "cw::skein_lines_kernel<4, false>") : "cw::skein_blocks_kernel<4, ...>"));
 #undef CW_LAUNCH
 #undef CW_LAUNCH_LINES
     return hipGetLastError();

@@ -153,6 +153,10 @@ static void *worker(void *arg)
     /* offload path: a span of units per call keeps the device's pipeline busy; slot path: one unit, like the reference */
     size_t span = gpu_offload ? ((size_t)8 << 30) / unit_bytes : 1; /* 16 chunks of the library's pipeline per call: its fill and drain (~25 ms) once per 8 GiB */
     if (span == 0) span = 1;
+    {   /* never more than this worker's device has to offer: a 226 MB dataset does not page-lock 8.6 GiB per worker */
+        const size_t shard = shard_end[dev] - shard_next[dev]; /* (set before the workers start; read-only until the start barrier) */
+        if (gpu_offload && span > shard) span = shard ? shard : 1;
+    }
     const size_t span_blocks = span * (size_t)read_block_factor;
     if (cw_set_device(dev) != CW_OK) { fprintf(stderr, "libcwhc: %s\n", cw_last_error()); exit(2); }
     uint8_t *hashes = (uint8_t *)malloc(db * span_blocks);
@@ -258,6 +262,13 @@ int main(int argc, char **argv)
     if (n_threads < 1 || read_block_factor < 1 || block_size < 1 || block_size > CW_MAX_BLOCK_BYTES)
         usage(argv[0], "threads and read-blocks must be >= 1, block-size in 1..65536");
     if (n_devices < 1 || n_devices > MAX_DEVICES) usage(argv[0], "devices must be 1..16");
+    {   /* fail early and loudly when the node has fewer devices than asked for: before any file is read or buffer pinned */
+        const int have = cw_device_count();
+        if (have < n_devices) {
+            fprintf(stderr, "libcwhc: %d device(s) asked for, %d usable%s\n", n_devices, have, have ? "" : " (no HIP device)");
+            return 2;
+        }
+    }
     if (n_threads < n_devices) n_threads = n_devices; /* every device needs a worker */
     /* --c-threads counts the reference's compute threads.  With the work on the device a worker only feeds one pipeline (three
      * 512 MiB slots of device memory, an 8.6 GiB page-locked output span), and a second pipeline on the same device shares the same

@@ -117,12 +117,15 @@ int main(int argc, char **argv)
     static const struct option opts[] = {
         {"devices", required_argument, 0, 'D'}, {"blocks-per-gpu", required_argument, 0, 'n'}, {"block-size", required_argument, 0, 'b'},
         {"steps", required_argument, 0, 's'},   {"warmup", required_argument, 0, 'w'},         {"hash-alg", required_argument, 0, 'H'},
-        {"comp-alg", required_argument, 0, 'C'}, {"data", required_argument, 0, 'd'},          {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+        {"comp-alg", required_argument, 0, 'C'}, {"data", required_argument, 0, 'd'},          {"help", no_argument, 0, 'h'},
+        {"blocks", required_argument, 0, 'N'}, {0, 0, 0, 0}};
+    size_t total_given = 0; /* --blocks: the whole stream's length; shards then differ by one block when devices do not divide it */
     int o;
-    while ((o = getopt_long(argc, argv, "D:n:b:s:w:H:C:d:h", opts, NULL)) != -1) {
+    while ((o = getopt_long(argc, argv, "D:n:N:b:s:w:H:C:d:h", opts, NULL)) != -1) {
         switch (o) {
         case 'D': n_dev = atoi(optarg); break;
         case 'n': blocks_per_gpu = (size_t)atol(optarg); break;
+        case 'N': total_given = (size_t)atol(optarg); break;
         case 'b': block_size = (size_t)atol(optarg); break;
         case 's': steps = atoi(optarg); break;
         case 'w': warmup = atoi(optarg); break;
@@ -130,7 +133,7 @@ int main(int argc, char **argv)
         case 'C': comp_name = optarg; break;
         case 'd': mixed = strcmp(optarg, "mixed") == 0; break;
         default:
-            fprintf(stderr, "Usage: %s [--devices N] [--blocks-per-gpu B] [--block-size S] [--steps K] [--warmup W] [-H skein|skein512|sha256mb] "
+            fprintf(stderr, "Usage: %s [--devices N] [--blocks-per-gpu B | --blocks TOTAL] [--block-size S] [--steps K] [--warmup W] [-H skein|skein512|sha256mb] "
                             "[-C lz4|lzf] [--data random|mixed]\n", argv[0]);
             return o == 'h' ? 0 : 1;
         }
@@ -158,7 +161,9 @@ int main(int argc, char **argv)
 
     db = cw_digest_bytes(hash_alg);
     stride = (cw_compress_bound(comp_alg, block_size) + 15) / 16 * 16;
-    const size_t total_blocks = blocks_per_gpu * (size_t)n_dev;
+    if (total_given && total_given < (size_t)n_dev) { fprintf(stderr, "--blocks: at least one block per device\n"); return 1; }
+    const size_t total_blocks = total_given ? total_given : blocks_per_gpu * (size_t)n_dev;
+    if (total_given) blocks_per_gpu = total_blocks / (size_t)n_dev; /* (reported; the shards are [g*N/G, (g+1)*N/G)) */
     ranks = (rank_t *)calloc((size_t)n_dev, sizeof(rank_t));
     shard_max = 0;
     for (int g = 0; g < n_dev; g++) {
@@ -189,9 +194,9 @@ int main(int argc, char **argv)
     const double secs = t1 - t0, in_bytes = (double)total_blocks * (double)block_size * steps;
     const uint64_t ms = (uint64_t)(secs * 1000.0);
     printf("%s|%s|%llu|%llu\n", hash_name, comp_name, (unsigned long long)ms, (unsigned long long)(ms ? in_bytes / 1048576.0 * 1000.0 / (double)ms : 0));
-    printf("{\"n_gpus\": %d, \"blocks_per_gpu\": %zu, \"block_bytes\": %zu, \"steps\": %d, \"data\": \"%s\", \"GBps\": %.2f, \"ms_per_step\": %.3f, "
+    printf("{\"n_gpus\": %d, \"blocks\": %zu, \"blocks_per_gpu\": %zu, \"block_bytes\": %zu, \"steps\": %d, \"data\": \"%s\", \"GBps\": %.2f, \"ms_per_step\": %.3f, "
            "\"bytes_out\": %llu, \"ratio\": %.4f, \"digest_fold\": \"%016llx\", \"all_devices_agree\": %s, \"gather\": \"RCCL ncclAllGather + ncclAllReduce\"}\n",
-           n_dev, blocks_per_gpu, block_size, steps, mixed ? "mixed" : "random", in_bytes / secs / 1e9, secs / steps * 1e3,
+           n_dev, total_blocks, blocks_per_gpu, block_size, steps, mixed ? "mixed" : "random", in_bytes / secs / 1e9, secs / steps * 1e3,
            (unsigned long long)totals[0], (double)total_blocks * (double)block_size / (double)totals[0], (unsigned long long)ranks[0].fold,
            agree ? "true" : "false");
     for (int g = 0; g < n_dev; g++) {

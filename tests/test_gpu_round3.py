@@ -115,3 +115,85 @@ def test_lzf_lane_share_claim_that_is_never_seen_ends_in_an_exact_batch(cw, orac
         for i in range(0, nb, 7):
             z = int(osz[i])
             assert slots[i, :z].tobytes() == opay[i, :z].tobytes(), i
+
+
+def _sweep_data():
+    rng = np.random.default_rng(5)
+    sparse = rng.integers(0, 256, 3 * 65536, dtype=np.uint8)
+    sparse[1000:1016] = sparse[200:216]
+    sparse[70000:70300] = 7
+    noise = rng.integers(0, 256, 2 * 65536, dtype=np.uint8).tobytes()
+    return (corpus_file("lcet10.txt")[:6 * 65536] + bytes(65536) + corpus_file("kennedy.xls")[:5 * 65536] + corpus_file("ptt5")[:3 * 65536]
+            + corpus_file("sum")[:32768] * 2 + sparse.tobytes() + noise + corpus_file("alice29.txt")[:2 * 65536])
+
+
+LZ4_KNOBS = [
+    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0),                                                   # the wavefront parser alone
+    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=1, CW_LZ4_LANES=0),                                    # register-table parsers, each taking the whole queue
+    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0),
+    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_LZ4_LANES=0),
+    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_VTAB_WPC=1, CW_LZ4_LANES=0),
+    dict(CW_LZ4_VTAB=2, CW_VTAB_GEN=3, CW_LZ4_LANES=0),                                    # beside the wavefront parser (the default regime)
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LZ4_LANES_RING=1),       # lane-per-block parsers, each taking the whole queue
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LZ4_LANES_RING=2),
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LZ4_LANES_RING=4),
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LZ4_LANES_RING=8),
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LZ4_LANES_RING=0),
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LZ4_LANES_RING=0, CW_LZ4_LANES_FP=0),
+    dict(CW_LZ4_VTAB=0, CW_LANES_CONCURRENT=0, CW_LZ4_LANES=1, CW_LANES_WPC=1),
+    dict(CW_LZ4_LANES=1),                                                                  # all three side by side on one queue, no reserve
+    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0, CW_LZ4_PARSE="fp"),                                # the fingerprint wavefront parser (diagnostic variant)
+    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0, CW_LZ4_PARSE="fp", CW_LZ4_HEADW=32),
+    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0, CW_LZ_FORCE_REDO=1),                               # every block through the first-generation redo pass
+]
+LZF_KNOBS = [
+    dict(CW_LZF_LANES=0),
+    dict(CW_LZF_LANES=1),
+    dict(CW_LZF_LANES=1, CW_LANES_WPC=1),
+    dict(CW_LZF_LANES=1, CW_LZF_ROUND=16),
+    dict(CW_LZF_LANES=1, CW_LZF_ROUND=5, CW_LANES_RESERVE=10),
+    dict(CW_LZF_LANES=0, CW_LZ_FORCE_REDO=1),
+    dict(CW_LZF_MODE="table"),
+]
+
+
+@pytest.mark.parametrize("comp,knob_sets", [("lz4", LZ4_KNOBS), ("lzf", LZF_KNOBS)])
+def test_every_parser_variant_equals_the_oracle_in_one_process(cw, oracle, comp, knob_sets):
+    """Every parser the launch policy can pick, forced through cw_tune_set in ONE process (round 2 needed a subprocess per setting:
+    the knobs were read once per process), each compared with the ORACLE -- sizes and payload bytes of every block -- at block sizes on
+    both sides of the LDS-staging limit, an odd size included."""
+    data = _sweep_data()
+    want = {}
+    for bs in (65536, 16384, 8192, 4096, 1000):
+        blocks = [data[i * bs:(i + 1) * bs] for i in range(len(data) // bs)]
+        want[bs] = [oracle.lz4_compress(b) if comp == "lz4" else oracle.lzf_compress(b) for b in blocks]
+    seen = set()
+    for knobs in knob_sets:
+        with cw.tuned(**knobs):
+            for bs, exp in want.items():
+                sizes, payload = cw.compress_blocks(comp, data[: len(exp) * bs], bs)
+                names = cw.profile_kernels()["codec"]
+                seen.add(names)
+                assert [int(z) for z in sizes] == [len(e) for e in exp], (knobs, bs, names)
+                for i, e in enumerate(exp):
+                    assert payload[i, : len(e)].tobytes() == e, (knobs, bs, i, names)
+    joined = " | ".join(sorted(seen))
+    if comp == "lz4":
+        for k in ("lz4_vtab_kernel", "lz4_vtab2_kernel", "lz4_vtab3_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
+                  "lz4_lanes_ring_kernel<8>", "lz4_lanes_kernel<0>", "lz4_lanes_kernel<1>", "lz4_lanes_kernel<2>", "lz4_parse_fp_kernel<32>", "lz4_parse_kernel<true>"):
+            assert k in joined, (k, joined)
+    else:
+        for k in ("lzf_lanes_kernel<true> [side stream]", "lzf_lanes_kernel<false>", "lzf_parse_kernel", "lzf_chain_kernel<true>", "lzf_chain_kernel<false>"):
+            assert k in joined, (k, joined)
+
+
+def test_tune_set_rejects_foreign_names_and_reset_restores_defaults(cw):
+    L = cw.lib()
+    assert L.cw_tune_set(b"PATH", b"x") != 0
+    cw.tune_set("CW_LZ4_VTAB", 0)
+    data = corpus_file("alice29.txt")[:4 * 65536]
+    cw.compress_blocks("lz4", data, 65536)
+    assert "vtab" not in cw.profile_kernels()["codec"]
+    cw.tune_reset()
+    cw.compress_blocks("lz4", data, 65536)
+    assert "vtab" in cw.profile_kernels()["codec"]

@@ -86,11 +86,50 @@ def test_mgpu_stream_three_fake_devices_under_sanitizers(oracle, kind):
 
 
 @pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_mgpu_stream_eight_fake_devices_uneven_shards_under_sanitizers(oracle, kind):
+    """The shape an 8-GPU node will use (BASELINE configs[4]) with a stream the devices do not divide: 8 rank threads, shards of 4 and 5
+    blocks ([g*N/8, (g+1)*N/8)), every rank's digests padded to the largest shard for the all-gather, the fold over the padded
+    layout equal on every device and equal to the oracle's over the whole stream."""
+    bs, total, G = 4096, 37, 8
+    lines = _run(f"{kind}_mgpu_stream", ["--devices", str(G), "--blocks", str(total), "--block-size", str(bs), "--steps", "2", "--warmup", "1",
+                                        "--data", "mixed", "-H", "skein512", "-C", "lz4"], G)
+    rep = json.loads(lines[-1])
+    data = oracle.gen_mixed_blocks(0xC0FFEE, 0, total, bs)
+    out, fold = 0, np.uint64(0)
+    for i in range(total):
+        blk = data[i * bs:(i + 1) * bs].tobytes()
+        out += len(oracle.lz4_compress(blk))
+        fold ^= np.bitwise_xor.reduce(np.frombuffer(oracle.skein512(blk, 512), dtype="<u8"))
+    assert rep["n_gpus"] == G and rep["blocks"] == total and rep["bytes_out"] == out
+    assert int(rep["digest_fold"], 16) == int(fold) and rep["all_devices_agree"]
+
+
+@pytest.mark.parametrize("kind", ["tsan"])
+def test_driver_eight_fake_devices_under_tsan(oracle, kind):
+    """hashandcompress --devices 8 with 9 worker threads over units the devices do not divide (TSan)."""
+    files = ["kennedy.xls", "ptt5", "sum"]
+    paths = [os.path.join(GOLDEN, "corpus", "canterbury", f) for f in files]
+    lines = _run(f"{kind}_hashandcompress", ["-v", "-g", "true", "--devices", "8", "-c", "9", "-r", "1", "--block-size=65536", "-H", "skein512", "-C", "lz4"] + paths, 8)
+    nblocks, out, fold = _expected(oracle, files, 65536, 1, "skein512", "lz4")
+    assert nblocks % 8 != 0
+    assert lines[1] == f"blocks={nblocks} in={nblocks * 65536} out={out} fold={fold:016x}"
+    assert lines[2] == f"devices=8 in={nblocks * 65536} out={out} (ncclAllReduce over the per-device totals)"
+
+
+def test_more_devices_than_present_fails_early_and_loudly():
+    """--devices beyond cw_device_count(): an error message and a non-zero exit before any work."""
+    for exe, args in (("asan_mgpu_stream", ["--devices", "9", "--blocks-per-gpu", "4", "--block-size", "4096"]),
+                      ("asan_hashandcompress", ["-g", "true", "--devices", "9", os.path.join(GOLDEN, "corpus", "canterbury", "sum")])):
+        r = subprocess.run([os.path.join(B, exe)] + args, capture_output=True, text=True, timeout=120, env={**ENV, "CW_STUB_DEVICES": "8"})
+        assert r.returncode != 0 and "9" in r.stderr and ("usable" in r.stderr or "device" in r.stderr), (exe, r.stderr[-500:])
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
 def test_perf_harnesses_under_sanitizers(kind, tmp_path):
     d = tmp_path / "data"
     d.mkdir()
     (d / "a.bin").write_bytes(corpus_file("fields.c")[:8192] + corpus_file("sum")[:8192])
-    lines = _run(f"{kind}_hashing_perf", [str(d)])
-    assert any("|Skein256|" in ln for ln in lines) and any("|Sha256MB|" in ln for ln in lines)
+    lines = _run(f"{kind}_hashing_perf", ["--verify", str(d)])
+    assert any("|Skein256|" in ln for ln in lines) and any("|Sha256MB|" in ln for ln in lines) and sum(ln.startswith("verify|") for ln in lines) == 3
     lines = _run(f"{kind}_compression_perf", ["-4", "-f", str(d / "a.bin")])
     assert lines and all(ln.split("|")[0] in ("lz4", "lzf") for ln in lines if "|" in ln)
