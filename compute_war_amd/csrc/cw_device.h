@@ -35,11 +35,15 @@ struct ClockScope {
     }
 };
 #define CW_CLOCK_SCOPE(buf) ClockScope clock_scope_(buf, blockIdx.x)
+// keyed: the kClockSlots records are cut into 8 groups of 128, one per `key` (the slice kernel's launch index within a pass), so
+// that the launches that overlap the codec and those that run after it are reported apart
+#define CW_CLOCK_SCOPE_KEYED(buf, key) ClockScope clock_scope_(buf, ((unsigned)(key) % 8u) * 128u + blockIdx.x % 128u)
 // which: 0 = the Skein slice kernel, 1 = the LZ4 span scan; out = kClockSlots x {m0, r0, m1, r1}
 hipError_t skein_clock_read(unsigned long long *out);
 hipError_t lz4_clock_read(unsigned long long *out);
 #else
 #define CW_CLOCK_SCOPE(buf) do { } while (0)
+#define CW_CLOCK_SCOPE_KEYED(buf, key) do { } while (0)
 #endif
 
 // Key of the per-(device, stream) scratch the launch sequences keep (the NULL stream exists once per device).  Every

@@ -684,6 +684,12 @@ __device__ __forceinline__ void cut64_v(uint32_t d1, uint32_t d2, uint32_t d3, u
     lo = __builtin_amdgcn_alignbit(v2, v1, sh);
     hi = __builtin_amdgcn_alignbit(v3, v2, sh);
 }
+// a candidate's window: 32 bytes in scalar registers
+struct CandWin {
+    u32x8 s;
+    template <int I> __device__ __forceinline__ uint32_t dw() const { return to_v(s[I]); }
+    template <int I> __device__ __forceinline__ void cut64(uint32_t sh, uint32_t &lo, uint32_t &hi) const { cut64_v(s[I], s[I + 1], s[I + 2], sh, lo, hi); }
+};
 // number of equal low bytes of two 8-byte values (0..8), on the VALU
 __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi)
 {
@@ -692,6 +698,9 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
 }
 } // namespace
 
+// (Tried and dropped: the candidate's bytes through the VECTOR memory path -- two bounds-checked buffer loads at a wave-uniform offset,
+// compared on the VALU -- on the theory that the scalar cache's few outstanding misses were the queue: text, 64 KiB, 8 Ki blocks
+// 20.8 -> 18.4 GB/s, 1,024 blocks 8.65 -> 7.26: the vector path's latency is simply longer.)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(CW_VT_COMPILER_VGPRS)))
 lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                  uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t min_queued,
@@ -738,10 +747,11 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             const uint32_t v = cut32(wp[0], wp[1], psh);                                                                       \
             const uint32_t cand = vt3_exchange((v * 2654435761u) >> 19, cur, k_ffff);                                          \
             const uint32_t cb4 = cand & ~3u, csh = (cand & 3u) * 8u, fb4 = (FIP) & ~3u;                                         \
-            u32x8 wc, wq;                                                                                                      \
+            CandWin wc;                                                                                                        \
+            u32x8 wq;                                                                                                          \
             asm volatile("s_buffer_load_dwordx8 %0, %2, %3\n\ts_buffer_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"      \
-                         : "=&s"(wc), "=&s"(wq) : "s"(rs), "s"(cb4), "s"(fb4));                                                \
-            const bool hit = cut32(wc[0], wc[1], csh) == v;
+                         : "=&s"(wc.s), "=&s"(wq) : "s"(rs), "s"(cb4), "s"(fb4));                                              \
+            const bool hit = cut32(wc.s[0], wc.s[1], csh) == v;
 #define CW_VT3_ADVANCE(FIP)                                                                                                    \
             if (fb4 != pb4) { wp = wq; pb4 = fb4; }                                                                            \
             cur = (FIP);
@@ -749,7 +759,7 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             for (;;) { // one sequence per iteration
                 // ---- search: probe cur, then positions with a stride that grows every 64 misses ----
                 uint32_t mcur = 0, mcand = 0, mpsh = 0, mcsh = 0, mcb4 = 0;
-                u32x8 mwc;
+                CandWin mwc;
                 bool found = false;
                 {
                     uint32_t step = 1, nb = 64;
@@ -775,7 +785,7 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                             uint32_t fp = sc_load4(rs, pb4 - 4u), fc = sc_load4(rs, mcb4 - 4u);
                             sc_wait3(fp, fc);
                             const uint32_t bp = __builtin_amdgcn_alignbit(to_v(wp[0]), to_v(fp), mpsh);
-                            const uint32_t bc = __builtin_amdgcn_alignbit(to_v(mwc[0]), to_v(fc), mcsh);
+                            const uint32_t bc = __builtin_amdgcn_alignbit(mwc.template dw<0>(), to_v(fc), mcsh);
                             const uint32_t y = bp ^ bc;
                             const uint32_t b = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
                             back = min(b, room);
@@ -798,12 +808,12 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                     {
                         uint32_t plo, phi, clo, chi;
                         cut64_v(wp[1], wp[2], wp[3], mpsh, plo, phi);
-                        cut64_v(mwc[1], mwc[2], mwc[3], mcsh, clo, chi);
+                        mwc.template cut64<1>(mcsh, clo, chi);
                         mc = equal_bytes_v(plo, phi, clo, chi);
                         const uint32_t lim = to_v(matchlimit - kMinMatch) - vcur;
                         if (__builtin_amdgcn_readfirstlane((uint32_t)(mc == 8 && lim > 8))) {
                             cut64_v(wp[3], wp[4], wp[5], mpsh, plo, phi);
-                            cut64_v(mwc[3], mwc[4], mwc[5], mcsh, clo, chi);
+                            mwc.template cut64<3>(mcsh, clo, chi);
                             mc = 8u + equal_bytes_v(plo, phi, clo, chi);
                             if (__builtin_amdgcn_readfirstlane((uint32_t)(mc == 16 && lim > 16))) {
                                 uint32_t m2 = 16;

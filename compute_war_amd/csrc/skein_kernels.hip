@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(CW_SKEIN_THREADS)
 skein_slice_kernel(const uint8_t *__restrict__ src, size_t block_bytes, size_t src_stride, size_t nblocks, SkeinIV iv,
                    uint8_t *__restrict__ digests, unsigned digest_bytes, uint64_t *__restrict__ state, size_t s_begin, size_t s_end)
 {
-    CW_CLOCK_SCOPE(g_clock_skein);
+    CW_CLOCK_SCOPE_KEYED(g_clock_skein, s_begin / (s_end - s_begin ? s_end - s_begin : 1)); // (the launch's index within its pass)
     constexpr unsigned BB = NW * 8, SPL = 128 / BB, HS = SPL / 2;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nblocks) return;

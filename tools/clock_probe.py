@@ -37,12 +37,12 @@ sizes = torch.zeros(a.nb, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 
 
-def clocks(which):
+def clocks(which, lo=0, hi=1024):
     buf = (C.c_ulonglong * 4096)()
     L.cw_debug_clock_read.argtypes = [C.c_int, C.c_void_p]
     assert L.cw_debug_clock_read(which, buf) == 0
     out = []
-    for i in range(1024):
+    for i in range(lo, hi):
         m0, r0, m1, r1 = buf[4 * i:4 * i + 4]
         if r1 > r0 and m1 > m0 and (r1 - r0) > 1000:   # > 10 us of 100 MHz ticks
             out.append((m1 - m0) / (r1 - r0) * 100e6 / 1e9)
@@ -64,6 +64,13 @@ def run(name, fn):
         c = clocks(which)
         if c:
             res[k] = {"GHz_median": round(statistics.median(c), 3), "GHz_min": round(min(c), 3), "GHz_max": round(max(c), 3), "workgroups": len(c)}
+    # the hash runs as 8 launches per pass; the stamps are kept per launch index (128 workgroups each): in the fused call the first
+    # launches overlap the codec's scan, the last ones run after it has ended
+    per = []
+    for k in range(8):
+        c = clocks(0, 128 * k, 128 * (k + 1))
+        per.append(round(statistics.median(c), 3) if c else None)
+    res["skein_slice_kernel_by_launch_GHz"] = per
     return res
 
 
