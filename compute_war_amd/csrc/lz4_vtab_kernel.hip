@@ -698,6 +698,11 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
 }
 } // namespace
 
+// (Tried and dropped: two probes per memory round trip -- while probe A's candidate is on its way, probe B is carried out as if A had
+// missed (its table exchange behind A's, both candidates and the next window requested together, B's write taken back when A hits):
+// one wait per sequence instead of two on text, bit-exact, and slower: text, 64 KiB, 1,024 / 3,233 / 8,192 blocks 8.63 / 17.1 / 20.8 ->
+// 6.77 / 12.7 / 15.1 GB/s.  A sequence's time is its ~190 dependent instructions, not its memory waits; the second exchange, the
+// third window and the scalar registers they spill cost more than the wait they save.)
 // (Tried and dropped: the candidate's bytes through the VECTOR memory path -- two bounds-checked buffer loads at a wave-uniform offset,
 // compared on the VALU -- on the theory that the scalar cache's few outstanding misses were the queue: text, 64 KiB, 8 Ki blocks
 // 20.8 -> 18.4 GB/s, 1,024 blocks 8.65 -> 7.26: the vector path's latency is simply longer.)

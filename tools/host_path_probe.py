@@ -31,14 +31,10 @@ hs, hp = L.cw_host_alloc(nb * a.bs), L.cw_host_alloc(cap)
 dev = torch.empty(nb * a.bs, dtype=torch.uint8, device="cuda")
 if a.data == "random":
     cw.dev_gen_random(0xC0FFEE, 0, nb, a.bs, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
-else:  # the in-tree corpora, whole 64 KiB blocks of every file, tiled
-    import glob
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "corpus")
-    parts = []
-    for f in sorted(glob.glob(os.path.join(root, "*", "*"))):
-        b = open(f, "rb").read()
-        parts.append(b[: len(b) // 65536 * 65536])
-    tile = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8).cuda()
+else:  # the bench legs' corpus tile (canterbury + canterbury-large, whole 64 KiB blocks of every file), tiled
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    tile = torch.frombuffer(bytearray(bench.corpus_tile()[0]), dtype=torch.uint8).cuda()
     for o in range(0, nb * a.bs, tile.numel()):
         k = min(tile.numel(), nb * a.bs - o)
         dev[o:o + k] = tile[:k]
