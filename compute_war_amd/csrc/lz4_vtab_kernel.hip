@@ -703,6 +703,11 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
 // one wait per sequence instead of two on text, bit-exact, and slower: text, 64 KiB, 1,024 / 3,233 / 8,192 blocks 8.63 / 17.1 / 20.8 ->
 // 6.77 / 12.7 / 15.1 GB/s.  A sequence's time is its ~190 dependent instructions, not its memory waits; the second exchange, the
 // third window and the scalar registers they spill cost more than the wait they save.)
+// (Tried and dropped for blocks up to 8 KiB: the block staged in LDS beside the register table (4 KiB of LDS per wavefront, so all 16
+// wavefronts per CU fit), every byte of the parse an LDS read and the arithmetic on the VALU: bit-exact, 28 GB/s alone on the 4 KiB corpus --
+// more than any other single parser there (LDS-resident wavefront parser 25.6, second-generation register-table kernel 17.8) and linear
+// in its wavefronts per CU (8 / 12 / 16: 17 / 23.5 / 28), i.e. bound by the chain of one sequence -- but beside the parsers it would
+// have to share the CU with it adds nothing: 51,728 blocks 30.0 against 29.5 GB/s, 1 Mi blocks 44.9 against 44.9.)
 // (Tried and dropped: the candidate's bytes through the VECTOR memory path -- two bounds-checked buffer loads at a wave-uniform offset,
 // compared on the VALU -- on the theory that the scalar cache's few outstanding misses were the queue: text, 64 KiB, 8 Ki blocks
 // 20.8 -> 18.4 GB/s, 1,024 blocks 8.65 -> 7.26: the vector path's latency is simply longer.)
