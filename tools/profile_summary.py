@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEGS = {"headline": ("skein512", "lz4", 65536, 1 << 20, "random"),
         "mixed": ("skein512", "lz4", 65536, 65536, "mixed"),
         "corpus_skein512_lz4": ("skein512", "lz4", 65536, 65536, "corpus"),
+        "corpus_skein512_lz4_3233": ("skein512", "lz4", 65536, 3233, "corpus"),
+        "corpus_skein512_lz4_51728": ("skein512", "lz4", 4096, 51728, "corpus"),
         "corpus_skein256_lz4_4k": ("skein", "lz4", 4096, 1 << 20, "corpus"),
         "corpus_sha256_lzf_4k": ("sha256mb", "lzf", 4096, 1 << 20, "corpus"),
         "corpus_sha256_lzf_64k": ("sha256mb", "lzf", 65536, 65536, "corpus")}
@@ -40,18 +42,18 @@ def pmc(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_default.json"))
     traffic = {"_note": "HBM bytes per STEP of a leg's kernels from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; "
                         "tools/collect_profiles.sh: bench.py --no-legs --steps 1 --warmup 0 at the leg's own size), summed over the launches "
                         "of the step. FETCH_SIZE is doubled (gfx950 counts 128-B requests of 16 B/lane streaming loads as 64 B, "
                         "MI355X_MICROARCH.md); for scattered narrow loads (the parse kernels' candidates) that correction is an upper bound. "
-                        "Counter collection serialises kernels: in the legs whose parsers run side by side (4 KiB blocks) the lane kernel, "
-                        "which starts first, takes every block but its reserve, so those sums describe that division of work, not the "
+                        "Counter collection serialises kernels: in the legs whose parsers run side by side the kernel that starts first "
+                        "takes every block but what it is told to leave, so those sums describe that division of work, not the "
                         f"timed one. Raw per-kernel sums: profiles/{tag}_pmc_summary.txt"}
-    lines = ["(rocprofv3 --pmc serialises kernels: where a lane kernel runs BESIDE the LDS-resident parser -- the 4 KiB legs -- it starts",
-             " first and takes every block but its reserve; per-block figures divide by all blocks of the step)", ""]
+    lines = ["(rocprofv3 --pmc serialises kernels: where parsers run SIDE BY SIDE on one queue -- round 3: every LZ4 leg -- the kernel that starts",
+             " first takes every block but what it is told to leave; per-block figures divide by all blocks of the step)", ""]
     for leg, (h, c, bs, nb, kind) in LEGS.items():
         ks = os.path.join(src, f"prof_{leg}", "p_kernel_stats.csv")
         if os.path.exists(ks):
