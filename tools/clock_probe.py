@@ -85,6 +85,7 @@ out["hash_alone"] = run("hash", lambda: cw.dev_hash("skein512", src.data_ptr(), 
 out["hash_alone"].pop("lz4_scan_span_kernel", None)
 out["scan_alone"] = run("scan", lambda: cw.dev_compress("lz4", src.data_ptr(), a.bs, a.nb, dst.data_ptr(), stride, sizes.data_ptr(), s))
 out["scan_alone"].pop("skein_slice_kernel", None)
+out["scan_alone"].pop("skein_slice_kernel_by_launch_GHz", None)   # (stale stamps of the previous mode)
 out["fused"] = run("fused", lambda: cw.dev_hash_and_compress("skein512", "lz4", src.data_ptr(), a.bs, a.nb, dig.data_ptr(), dst.data_ptr(), stride,
                                                              sizes.data_ptr(), s))
 print(json.dumps(out, indent=1))
