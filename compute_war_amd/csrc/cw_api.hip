@@ -159,8 +159,8 @@ struct Slot {
     {
         src.release(); dst.release(); pack.release(); sizes.release(); offs.release(); dig.release();
         h_src.release(); h_meta.release(); h_pack.release();
-        if (stream) (void)hipStreamDestroy(stream);
-        if (side) (void)hipStreamDestroy(side);
+        if (stream) { cw::release_stream_workspaces(stream); (void)hipStreamDestroy(stream); }
+        if (side) { cw::release_stream_workspaces(side); (void)hipStreamDestroy(side); }
         if (fork) (void)hipEventDestroy(fork);
         if (join) (void)hipEventDestroy(join);
         if (ev_meta) (void)hipEventDestroy(ev_meta);
@@ -201,6 +201,7 @@ struct ThreadCtx {
         src.release(); dst.release(); dig.release(); sizes.release();
         for (Slot &s : slot) s.release();
         (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
+        cw::release_stream_workspaces(side); cw::release_stream_workspaces(stream);
         (void)hipStreamDestroy(side); (void)hipStreamDestroy(s_h2d); (void)hipStreamDestroy(s_d2h); (void)hipStreamDestroy(stream);
     }
 };
@@ -299,6 +300,15 @@ const char *cw::tune(const char *key)
         e = tune_env.emplace(key, std::make_pair(v != nullptr, std::string(v ? v : ""))).first;
     }
     return e->second.first ? e->second.second.c_str() : nullptr;
+}
+
+void cw::release_stream_workspaces(hipStream_t stream)
+{
+    (void)hipStreamSynchronize(stream); // nothing of the stream's may still use what is freed here
+    cw::lz4_release_stream(stream);
+    cw::lzf_release_stream(stream);
+    cw::pack_release_stream(stream);
+    cw::skein_release_stream(stream);
 }
 
 void cw::note_kernels(int kind, const char *names)
@@ -807,7 +817,10 @@ bool room_to_grow(const ThreadCtx &c, const HostJob &j, size_t big)
     if (c.slot[0].src.cap >= big * j.bb && c.slot[kSlots - 1].src.cap >= big * j.bb) return true; // grown before
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const size_t need = kSlots * big * (j.bb + 2 * j.d_stride + 64);
+    // + the lane parsers' tables on each slot stream (LZ4 4 GiB, LZF 8 GiB at most; lz4_kernel.hip / lzf_kernel.hip allocate them on the first
+    //   large chunk and fall back to the parsers without lanes when the device cannot give them)
+    const size_t lane_tabs = kSlots * (j.comp_alg == CW_COMP_LZF ? (size_t)8 << 30 : (size_t)4 << 30);
+    const size_t need = kSlots * big * (j.bb + 2 * j.d_stride + 64) + lane_tabs;
     return free_b > need + ((size_t)16 << 30);
 }
 

@@ -104,6 +104,13 @@ void skein_release_workspaces();
 void lz4_release_workspaces();
 void lzf_release_workspaces();
 void pack_release_workspaces();
+// the same for ONE stream of the current device: called by whoever owns the stream before destroying it, so that a short-lived
+// calling thread does not leave gigabytes of lane tables behind and a recycled stream handle does not inherit a stale entry
+void release_stream_workspaces(hipStream_t stream);
+void skein_release_stream(hipStream_t stream);
+void lz4_release_stream(hipStream_t stream);
+void lzf_release_stream(hipStream_t stream);
+void pack_release_stream(hipStream_t stream);
 hipError_t sum_sizes_launch(const uint32_t *sizes, size_t n, uint32_t raw_bytes, uint64_t *totals, hipStream_t stream);
 hipError_t gen_random_launch(uint64_t seed, uint64_t first_block, size_t nblocks, size_t block_bytes, uint8_t *dst,
                              hipStream_t stream);

@@ -2017,6 +2017,19 @@ void lz4_release_workspaces()
     ws_map.clear();
 }
 
+void lz4_release_stream(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(ws_lock);
+    auto it = ws_map.find(ws_key(stream));
+    if (it == ws_map.end()) return;
+    Workspace &w = it->second;
+    if (w.p) (void)hipFree(w.p);
+    if (w.lane_tabs) (void)hipFree(w.lane_tabs);
+    if (w.side) { (void)hipStreamDestroy(w.side); (void)hipEventDestroy(w.fork); (void)hipEventDestroy(w.join); }
+    if (w.side2) { (void)hipStreamDestroy(w.side2); (void)hipEventDestroy(w.fork2); (void)hipEventDestroy(w.join2); }
+    ws_map.erase(it);
+}
+
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {

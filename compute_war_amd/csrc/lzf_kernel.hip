@@ -1067,6 +1067,20 @@ void lzf_release_workspaces()
     link_map.clear();
 }
 
+void lzf_release_stream(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(link_lock);
+    auto it = link_map.find(ws_key(stream));
+    if (it == link_map.end()) return;
+    auto &w = it->second.s;
+    if (w.p) (void)hipFree(w.p);
+    if (w.counter) (void)hipFree(w.counter);
+    if (w.lane_tabs) (void)hipFree(w.lane_tabs);
+    if (w.handback) (void)hipFree(w.handback);
+    if (w.side) { (void)hipStreamDestroy(w.side); (void)hipEventDestroy(w.fork); (void)hipEventDestroy(w.join); }
+    link_map.erase(it);
+}
+
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream)
 {

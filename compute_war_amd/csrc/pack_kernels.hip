@@ -121,6 +121,15 @@ void pack_release_workspaces()
     ws_map.clear();
 }
 
+void pack_release_stream(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(ws_lock);
+    auto it = ws_map.find(ws_key(stream));
+    if (it == ws_map.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    ws_map.erase(it);
+}
+
 hipError_t pack_launch(const uint8_t *slots, size_t slot_stride, const uint32_t *sizes, size_t nblocks, uint8_t *packed,
                        uint64_t *offsets, hipStream_t stream)
 {

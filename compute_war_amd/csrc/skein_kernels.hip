@@ -482,6 +482,15 @@ void skein_release_workspaces()
     slice_map.clear();
 }
 
+void skein_release_stream(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(slice_lock);
+    auto it = slice_map.find(ws_key(stream));
+    if (it == slice_map.end()) return;
+    if (it->second.p) (void)hipFree(it->second.p);
+    slice_map.erase(it);
+}
+
 bool skein_sliced_applies(int nw, const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, const uint8_t *digests)
 {
     const size_t bb = (size_t)nw * 8;

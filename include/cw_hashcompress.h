@@ -121,7 +121,9 @@ int cw_hash_and_compress_packed(int hash_alg, int comp_alg, const void *src, siz
 /* Both forms run as a three-stage pipeline (host->device copy of chunk k+1 | kernels of chunk k | device->host copy of
  * chunk k-1: what HashOffload::Start()/Complete() were meant to be, HashOffload.h:26-40).  The copy engines read and
  * write page-locked host memory in place; other buffers go through pinned staging with one memcpy.  Chunks are 512 MiB
- * (4.6 GiB of device memory per calling thread and device); with page-locked buffers on both sides, chunks of blocks
+ * (4.6 GiB of device memory per calling thread and device, plus the codecs' per-stream scratch: up to 4 GiB (LZ4) / 8 GiB (LZF)
+ * of lane-parser tables on each of the three slot streams once a chunk is large enough for the lanes -- a device that cannot give
+ * them runs the call without the lanes instead of failing it); with page-locked buffers on both sides, chunks of blocks
  * above 4 KiB grow to 2 GiB once the first results show that the data compresses (18.5 GiB then), because the codecs
  * reach their rate only on tens of thousands of blocks at a time.  To get buffers the engines can use directly:       */
 /* initializeGpu() (:95-98) for the calling thread: its context on its device plus everything the batch path would allocate

@@ -197,3 +197,28 @@ def test_tune_set_rejects_foreign_names_and_reset_restores_defaults(cw):
     cw.tune_reset()
     cw.compress_blocks("lz4", data, 65536)
     assert "vtab" in cw.profile_kernels()["codec"]
+
+
+def test_short_lived_calling_threads_leave_no_device_memory_behind(cw, oracle):
+    """Every calling thread has its own context (streams, pipeline slots) and the codecs keep per-stream scratch; a thread that ends
+    must take both with it (the scratch of its streams stayed until cw_shutdown, gigabytes once lane tables exist)."""
+    import threading
+
+    import torch
+    data = (corpus_file("lcet10.txt") * 40)[:256 * 65536]   # 16 MiB: three pipeline chunks, codec workspaces on three slot streams
+    want = [len(oracle.lz4_compress(data[i * 65536:(i + 1) * 65536])) for i in range(4)]
+    result = {}
+
+    def work(tag):
+        d, sizes, _ = cw.hash_and_compress_blocks("skein512", "lz4", data, 65536)
+        result[tag] = [int(z) for z in sizes[:4]]
+
+    t = threading.Thread(target=work, args=("warm",)); t.start(); t.join()   # first use may allocate process-wide state
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(4):
+        t = threading.Thread(target=work, args=(k,)); t.start(); t.join()
+        assert result[k] == want
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)   # four more threads came and went: nothing of theirs is left

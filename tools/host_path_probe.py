@@ -54,6 +54,8 @@ if a.warm:
     del scratch
     print(f"warm-up copy over the output buffer: {(time.perf_counter() - t0) * 1e3:.0f} ms", flush=True)
 for i in range(a.passes):
+    cw.profile_enable(True)
+    cw.profile_read(reset=True)
     t0 = time.perf_counter()
     cw.ops.check(L.cw_hash_and_compress_packed(H, Cc, hs, a.bs, nb, dig.ctypes.data, hp, cap, offs.ctypes.data, sizes.ctypes.data))
     t = time.perf_counter() - t0

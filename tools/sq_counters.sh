@@ -2,7 +2,8 @@
 # SQ counter passes (rocprofv3 --pmc, kernel trace only, one counter set per run: tools/pmc_parse.sh) over the kernels the review
 # asked about, summarised per kernel and launch into gpurun_out/sq_counters.txt (tracked copy: profiles/<round>_sq_counters.txt).
 # Counter collection serialises kernels, so "beside" regimes cannot be measured this way: each kernel is measured alone.
-#   gpurun -- 'bash tools/sq_counters.sh'
+#   gpurun -- 'bash tools/sq_counters.sh'        (round 2's kernels)
+#   gpurun -- 'bash tools/sq_counters.sh vtab'   (round 3: the register-table LZ4 parsers)
 O=gpurun_out/sq_counters.txt
 : > $O
 run() { # tag, kernel filter, blocks, perf_probe args...
@@ -13,6 +14,13 @@ run() { # tag, kernel filter, blocks, perf_probe args...
     echo >> $O
     rm -rf gpurun_out/pmc_${tag}_*
 }
+if [ "$1" = "vtab" ]; then # round 3: the register-table parsers, each taking the whole queue (CW_LZ4_VTAB=1), 16 wavefronts per CU
+    CW_LZ4_VTAB=1 CW_VTAB_GEN=1 CW_LZ4_LANES=0 run vtab_gen1 lz4_vtab_kernel   8192 --alg none --comp lz4 --bs 65536 --data text
+    CW_LZ4_VTAB=1 CW_VTAB_GEN=3 CW_LZ4_LANES=0 run vtab_gen3 lz4_vtab3_kernel  8192 --alg none --comp lz4 --bs 65536 --data text
+    CW_LZ4_VTAB=1 CW_VTAB_GEN=2 CW_LZ4_LANES=0 run vtab_gen2_4k lz4_vtab2_kernel 65536 --alg none --comp lz4 --bs 4096 --data text
+    cat $O
+    exit 0
+fi
 run parse_wave   lz4_parse_kernel      8192   --alg none --comp lz4 --bs 65536 --data text
 run lanes_k2     lz4_lanes_ring_kernel 16384  --alg none --comp lz4 --bs 65536 --data text
 run lanes_k1     lz4_lanes_ring_kernel 65536  --alg none --comp lz4 --bs 65536 --data text
