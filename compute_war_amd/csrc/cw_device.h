@@ -94,6 +94,9 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
 hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *dst, size_t dst_stride, uint32_t *sizes,
                            const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t max_queued, uint32_t reserve,
                            unsigned waves_per_cu, hipStream_t stream, const char **kernel_name);
+// the same scalar-thread parser with its table in LDS (ten wavefronts per CU): takes what is left of the queue
+hipError_t lz4_ltab_launch(const uint8_t *src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *dst, size_t dst_stride, uint32_t *sizes,
+                           const uint32_t *queue, uint32_t *counters, unsigned waves_per_cu, hipStream_t stream);
 hipError_t decompress_launch(int alg, const uint8_t *comp, size_t comp_stride, const uint32_t *sizes, size_t nblocks, uint8_t *dst,
                              size_t block_bytes, uint32_t *status, hipStream_t stream);
 // packed stream: offsets[i] = sum sizes[0..i) (nblocks + 1 entries); slot i copied to packed + offsets[i] (packed may be NULL)

@@ -1406,6 +1406,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // 23.9 / 25.1 / 26.1 / 26.5 GB/s against the lanes' 15.4 / 19.5 / 24.1 / 28.8), so the lanes start later than in round 2 (10,240), and from there on
 // they run BESIDE those two, leaving them kLaneShare blocks of the queue (49,152 blocks: 34.0 -> 40.7 GB/s, 131,072: 44.9 -> 48.3).
 constexpr uint32_t kLaneMidBlocks = 26624, kLaneWideBlocks = 98304; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
+constexpr bool kLtabDefault = true; // corpus, 64 KiB, alone on the queue: 8 Ki / 16 Ki / 48 Ki blocks 16.1 / 17.5 / 18.6 GB/s against the wavefront parser's 14.6 / 15.8 / 16.6; beside the register form 23.3 / 26.7 against 22.2 / 25.4
 constexpr uint32_t kLaneShare = 24576, kLaneShareWide = 32768;     // blocks of the queue the lanes leave to the other parsers (K = 2 / K = 1 regime)
 constexpr uint32_t kLaneMinSmall = 61440;  // LDS-staged blocks: lanes beside the LDS-resident parser from 60 Ki blocks on (64 Ki blocks of text: 28.5 against 25.7 GB/s)
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
@@ -2282,6 +2283,15 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
     const char *redo_env = tune("CW_LZ_FORCE_REDO");
     const uint32_t force_redo = redo_env && atoi(redo_env) > 0 ? 1u : 0u;
     if (!cut_only) {
+        // blocks read from global memory: the scalar-thread parser with its table in LDS (lz4_vtab3_kernel<true>) in the place of the round-2
+        // wavefront parser; CW_LZ4_LTAB=0 keeps the latter (and the forced-redo test knob and unaligned sources need it)
+        const char *lt_env = tune("CW_LZ4_LTAB");
+        const bool use_ltab = !staged && !use_fp && !force_redo && n >= 64 && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) == 0 &&
+                              (lt_env ? atoi(lt_env) != 0 : kLtabDefault);
+        if (use_ltab) {
+            note("cw::lz4_vtab3_kernel<true>");
+            if ((e = lz4_ltab_launch(src, n, src_stride, nblocks, dst, dst_stride, sizes, queue, counters, (unsigned)pwpc, stream)) != hipSuccess) return e;
+        } else {
         note(staged ? "cw::lz4_parse_kernel<true>" : use_fp ? "cw::lz4_parse_fp_kernel<%d>" : "cw::lz4_parse_kernel<false>", headw == 32 || headw == 8 ? headw : 16);
         if (staged)
             hipLaunchKernelGGL(lz4_parse_kernel<true>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
@@ -2299,6 +2309,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             hipLaunchKernelGGL(lz4_parse_kernel<false>, dim3((unsigned)grid), dim3(64), lds, stream, src, n, src_stride, nblocks, dst,
                                dst_stride, sizes, queue, counters, queue2, force_redo);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
     }
     if (vtab_used && vtab_beside) {
         if ((e = hipEventRecord(wsp.join2, wsp.side2)) != hipSuccess) return e;

@@ -651,6 +651,23 @@ __device__ __forceinline__ void vt3_put(uint32_t h, uint32_t pos, uint32_t k_fff
                  : [r] "s"(r), [l] "s"(l), [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
                  : "scc", CW_VT_CLOBBER);
 }
+// The same two operations on a table in LDS (LDSTAB form of the third kernel, below): slot h of 8192 x u16 at byte address
+// tab_lds + 2 h, touched by wave-uniform addresses (a broadcast read; every lane writes the same value).
+__device__ __forceinline__ uint32_t lt3_exchange(uint32_t tab_lds, uint32_t h, uint32_t pos)
+{
+    uint32_t old, t;
+    const uint32_t addr = tab_lds + 2u * h;
+    asm volatile("ds_read_u16 %[t], %[a]\n\t"
+                 "ds_write_b16 %[a], %[p]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_readfirstlane_b32 %[old], %[t]"
+                 : [old] "=s"(old), [t] "=&v"(t) : [a] "v"(addr), [p] "v"(pos) : "memory");
+    return old;
+}
+__device__ __forceinline__ void lt3_put(uint32_t tab_lds, uint32_t h, uint32_t pos)
+{
+    asm volatile("ds_write_b16 %[a], %[p]" :: [a] "v"(tab_lds + 2u * h), [p] "v"(pos) : "memory");
+}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 sc_load8(const u32x4 &rs, uint32_t off)
 {
@@ -711,6 +728,11 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
 // (Tried and dropped: the candidate's bytes through the VECTOR memory path -- two bounds-checked buffer loads at a wave-uniform offset,
 // compared on the VALU -- on the theory that the scalar cache's few outstanding misses were the queue: text, 64 KiB, 8 Ki blocks
 // 20.8 -> 18.4 GB/s, 1,024 blocks 8.65 -> 7.26: the vector path's latency is simply longer.)
+// LDSTAB: the same scalar-thread parser with its table in LDS (16 KiB per wavefront, ten per CU) instead of in registers.  It takes
+// the place of the round-2 wavefront parser (lz4_parse_kernel<false>) beside the register form for blocks read from global memory: a
+// table operation is two LDS instructions at a wave-uniform address instead of an exchange over 64 lanes with its lane-order check and
+// undo, and the chain of a sequence is this kernel's (~2,000 cycles) instead of that one's (2,500-3,100).
+template <bool LDSTAB>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(CW_VT_COMPILER_VGPRS)))
 lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                  uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t min_queued,
@@ -721,6 +743,9 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
     if (qcount < min_queued || qcount >= max_queued) return;
     const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
     const uint32_t k_ffff = to_v(0xFFFFu);
+    extern __shared__ __attribute__((aligned(16))) uint8_t ltab[]; // LDSTAB: the 8192 x u16 table
+    const uint32_t tab_lds = (uint32_t)reinterpret_cast<uintptr_t>(ltab);
+    (void)tab_lds; (void)k_ffff;
 
     for (;;) {
         uint32_t qi = qcount;
@@ -739,7 +764,13 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             rs.z = n;
             rs.w = 0x00020000u;
         }
-        vt_zero();
+        if constexpr (LDSTAB) {
+            __syncthreads(); // (one wavefront: orders the previous block's LDS traffic before the clearing stores)
+            for (uint32_t i = lane; i < (1u << 13) * 2u / 16u; i += 64) reinterpret_cast<uint4 *>(ltab)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        } else {
+            vt_zero();
+        }
 
         // wave-uniform state in vector registers: anchor, output position; a pending literal copy (per lane: the byte)
         uint32_t anchor = to_v(0), op = to_v(0);
@@ -755,7 +786,8 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 #define CW_VT3_PROBE(FIP)                                                                                                      \
             const uint32_t psh = (cur - pb4) * 8u;                                                                             \
             const uint32_t v = cut32(wp[0], wp[1], psh);                                                                       \
-            const uint32_t cand = vt3_exchange((v * 2654435761u) >> 19, cur, k_ffff);                                          \
+            const uint32_t cand = LDSTAB ? lt3_exchange(tab_lds, (v * 2654435761u) >> 19, cur)                                 \
+                                         : vt3_exchange((v * 2654435761u) >> 19, cur, k_ffff);                                 \
             const uint32_t cb4 = cand & ~3u, csh = (cand & 3u) * 8u, fb4 = (FIP) & ~3u;                                         \
             CandWin wc;                                                                                                        \
             u32x8 wq;                                                                                                          \
@@ -884,7 +916,8 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 
                     // ---- table: insert mend - 2, then the immediate re-test at mend ----
                     sc_wait3(wnext, wins);
-                    vt3_put((cut32(wins[0], wins[1], ((mend - 2u) & 3u) * 8u) * 2654435761u) >> 19, mend - 2u, k_ffff);
+                    if constexpr (LDSTAB) lt3_put(tab_lds, (cut32(wins[0], wins[1], ((mend - 2u) & 3u) * 8u) * 2654435761u) >> 19, mend - 2u);
+                    else vt3_put((cut32(wins[0], wins[1], ((mend - 2u) & 3u) * 8u) * 2654435761u) >> 19, mend - 2u, k_ffff);
                     wp = wnext; pb4 = nb4; cur = mend;
                     {
                         const uint32_t fip = cur + 1;
@@ -935,9 +968,9 @@ hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, si
     size_t grid = 256 * (size_t)(waves_per_cu ? waves_per_cu : 16);
     if (grid > nblocks) grid = nblocks;
     if (grid == 0) return hipSuccess;
-    if (kernel_name) *kernel_name = gen == 3 ? "cw::lz4_vtab3_kernel" : gen == 1 ? "cw::lz4_vtab_kernel" : "cw::lz4_vtab2_kernel";
+    if (kernel_name) *kernel_name = gen == 3 ? "cw::lz4_vtab3_kernel<false>" : gen == 1 ? "cw::lz4_vtab_kernel" : "cw::lz4_vtab2_kernel";
     if (gen == 3)
-        hipLaunchKernelGGL(lz4_vtab3_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
+        hipLaunchKernelGGL(lz4_vtab3_kernel<false>, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
                            min_queued, max_queued, reserve);
     else if (gen == 1)
         hipLaunchKernelGGL(lz4_vtab_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
@@ -945,6 +978,19 @@ hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, si
     else
         hipLaunchKernelGGL(lz4_vtab2_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
                            min_queued, max_queued, reserve);
+    return hipGetLastError();
+}
+
+// the scalar-thread parser with its table in LDS: ten single-wavefront workgroups per CU at most (16 KiB of LDS each)
+hipError_t lz4_ltab_launch(const uint8_t *src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *dst, size_t dst_stride, uint32_t *sizes,
+                           const uint32_t *queue, uint32_t *counters, unsigned waves_per_cu, hipStream_t stream)
+{
+    if ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) return hipErrorInvalidValue;
+    size_t grid = 256 * (size_t)(waves_per_cu && waves_per_cu < 10 ? waves_per_cu : 10);
+    if (grid > nblocks) grid = nblocks;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz4_vtab3_kernel<true>, dim3((unsigned)grid), dim3(64), (1u << 13) * 2u, stream, src, n, src_stride, dst, dst_stride, sizes, queue,
+                       counters, 0u, 0xFFFFFFFFu, 0u);
     return hipGetLastError();
 }
 

@@ -128,7 +128,8 @@ def _sweep_data():
 
 
 LZ4_KNOBS = [
-    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0),                                                   # the wavefront parser alone
+    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0),                                                   # the LDS-table scalar-thread parser alone (blocks > 4 KiB)
+    dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0, CW_LZ4_LTAB=0),                                    # round 2's wavefront parser alone
     dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=1, CW_LZ4_LANES=0),                                    # register-table parsers, each taking the whole queue
     dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0),
     dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_LZ4_LANES=0),
@@ -179,8 +180,8 @@ def test_every_parser_variant_equals_the_oracle_in_one_process(cw, oracle, comp,
                     assert payload[i, : len(e)].tobytes() == e, (knobs, bs, i, names)
     joined = " | ".join(sorted(seen))
     if comp == "lz4":
-        for k in ("lz4_vtab_kernel", "lz4_vtab2_kernel", "lz4_vtab3_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
-                  "lz4_lanes_ring_kernel<8>", "lz4_lanes_kernel<0>", "lz4_lanes_kernel<1>", "lz4_lanes_kernel<2>", "lz4_parse_fp_kernel<32>", "lz4_parse_kernel<true>"):
+        for k in ("lz4_vtab_kernel", "lz4_vtab2_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
+                  "lz4_lanes_ring_kernel<8>", "lz4_lanes_kernel<0>", "lz4_lanes_kernel<1>", "lz4_lanes_kernel<2>", "lz4_parse_fp_kernel<32>", "lz4_parse_kernel<true>", "lz4_parse_kernel<false>", "lz4_vtab3_kernel<true>", "lz4_vtab3_kernel<false>"):
             assert k in joined, (k, joined)
     else:
         for k in ("lzf_lanes_kernel<true> [side stream]", "lzf_lanes_kernel<false>", "lzf_parse_kernel", "lzf_chain_kernel<true>", "lzf_chain_kernel<false>"):
