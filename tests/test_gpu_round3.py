@@ -223,3 +223,39 @@ def test_short_lived_calling_threads_leave_no_device_memory_behind(cw, oracle):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (64 << 20), (free0, free1)   # four more threads came and went: nothing of theirs is left
+
+
+@pytest.mark.parametrize("bs", [5001, 65533, 4093, 70])
+def test_register_table_parsers_on_block_sizes_that_are_not_multiples_of_four(cw, oracle, bs):
+    """The scalar-thread parsers read the block through a buffer descriptor whose range check works on dwords: a block size that is not
+    a multiple of 4 (source stride rounded up, so that they accept the batch) must still give the oracle's bytes -- the last, partial dword
+    lies behind every position a match may reach."""
+    import torch
+    nb = 200
+    stride_src = (bs + 3) // 4 * 4
+    base = _sweep_data()
+    rng = np.random.default_rng(bs)
+    raw = np.zeros(nb * stride_src, dtype=np.uint8)
+    blocks = []
+    for i in range(nb):
+        o = int(rng.integers(0, len(base) - bs))
+        b = np.frombuffer(base[o:o + bs], dtype=np.uint8).copy()
+        if i % 5 == 0:
+            b[-9:] = b[-18:-9]          # a match that runs into the end of the block
+        raw[i * stride_src:i * stride_src + bs] = b
+        blocks.append(b.tobytes())
+    want = [oracle.lz4_compress(b) for b in blocks]
+    s = torch.cuda.current_stream().cuda_stream
+    dev = torch.from_numpy(raw).cuda()
+    dstride = (cw.compress_bound("lz4", bs) + 15) // 16 * 16
+    for knobs in (dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=1, CW_LZ4_LANES=0), dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0),
+                  dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_LZ4_LANES=0), dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0), dict()):
+        dst = torch.zeros(nb * dstride, dtype=torch.uint8, device="cuda")
+        sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        with cw.tuned(**knobs):
+            cw.dev_compress("lz4", dev.data_ptr(), bs, nb, dst.data_ptr(), dstride, sizes.data_ptr(), s, src_stride=stride_src)
+            torch.cuda.synchronize()
+            names = cw.profile_kernels()["codec"]
+        hz, hd = sizes.cpu().numpy(), dst.view(nb, dstride).cpu().numpy()
+        for i, e in enumerate(want):
+            assert int(hz[i]) == len(e) and hd[i, : len(e)].tobytes() == e, (knobs, bs, i, names)
