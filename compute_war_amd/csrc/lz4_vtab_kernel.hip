@@ -11,10 +11,10 @@
 // (entry h lives in register h >> 7, lane (h >> 1) & 63, half h & 1), so four such wavefronts fit a SIMD: 16 chains per CU
 // BESIDE the ten of the LDS -- with no memory traffic for the table at all.  A VGPR can only be indexed by a wave-uniform value
 // (s_set_gpr_idx_on), which is exactly what a scalar thread has: the parse below is the serial parser as it stands (oracle/lz4_oracle.c
-// restates it), every value wave-uniform and kept in SGPRs, the table touched through v_readlane_b32 / a one-lane v_mov_b32 on the
-// indexed register, the input read through the scalar data cache (s_buffer_load_dwordx8: bounds-checked by the buffer descriptor, so
-// no load reaches outside the block), and the 64 lanes used only where a block has width to offer: literal copies, long match
-// extensions, length bytes.
+// restates it), every value wave-uniform, the table touched through v_readlane_b32 / a one-lane v_mov_b32 on the indexed register, the
+// input read through the scalar data cache (s_buffer_load_dwordx8: bounds-checked by the buffer descriptor, so no load reaches outside
+// the block), and the 64 lanes used only where a block has width to offer: long match extensions, and the OUTPUT -- the parse records
+// its sequences and writes them out 64 at a time, a lane per output byte (emit_batch).
 //
 // The table registers are the physical VGPRs v64..v127, above the range the compiler may allocate (amdgpu_num_vgpr), named only in
 // inline assembly and declared as clobbered there.
@@ -55,75 +55,20 @@ __device__ __forceinline__ void vt_zero()
                  ::: CW_VT_CLOBBER);
 }
 
-// entry h <- pos; returns the previous entry.  All operands wave-uniform (SGPRs); EXEC is all ones on entry and on exit.
-__device__ __forceinline__ uint32_t vt_exchange(uint32_t h, uint32_t pos)
-{
-    const uint32_t r = h >> 7, l = (h >> 1) & 63u, sh = (h & 1u) << 4;
-    uint32_t w;
-    // (the register index applies to v_readlane_b32's source and to a one-lane v_mov_b32's destination on gfx950: tools/idxmode.hip)
-    asm volatile("s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\t"
-                 "v_readlane_b32 %0, " CW_VT_BASE ", %2\n\t"
-                 "s_set_gpr_idx_off"
-                 : "=s"(w) : "s"(r), "s"(l) : CW_VT_CLOBBER);
-    const uint32_t nw = (w & ~(0xFFFFu << sh)) | (pos << sh);
-    asm volatile("s_lshl_b64 exec, 1, %2\n\t"
-                 "s_set_gpr_idx_on %0, gpr_idx(DST)\n\t"
-                 "v_mov_b32 " CW_VT_BASE ", %1\n\t"
-                 "s_set_gpr_idx_off\n\t"
-                 "s_mov_b64 exec, -1"
-                 :: "s"(r), "s"(nw), "s"(l) : CW_VT_CLOBBER);
-    return (w >> sh) & 0xFFFFu;
-}
-
 // ---- the input through the scalar cache -------------------------------------------------------------------------------
-// 32 bytes at byte offset `off` (a multiple of 4; may have wrapped below zero) of the block described by rs; dwords outside
-// [0, num_records) read as zero.  The caller waits (sc_wait) before it uses them.
-__device__ __forceinline__ u32x8 sc_load32(const u32x4 &rs, uint32_t off)
+// s_buffer_load_*: bytes at byte offset `off` (a multiple of 4) of the block described by rs; dwords outside [0, num_records) read as
+// zero (an offset that wrapped below zero makes the WHOLE load read as zero: tools/sbuf.hip).
+// RULE: a scalar load and the s_waitcnt that covers it are ONE asm statement.  The compiler does not know that the destination
+// registers of an s_buffer_load in inline assembly are still in flight behind the statement: with the load in one statement and the
+// wait in a later one (as this file had it, to run the emission of a sequence under the next windows' latency) it is free to copy or
+// spill those registers in between -- and did, in the -DCW_VSTAMP build of the day: an `s_mov_b64` of the two dwords in front of the
+// emission read them before they had arrived once in ~40,000 sequences, and half of all blocks came out a few bytes wrong.  The
+// product build of the same source happened to have no such copy and passed every test.
+__device__ __forceinline__ u32x8 sc_load32_now(const u32x4 &rs, uint32_t off)
 {
     u32x8 v;
-    asm volatile("s_buffer_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(rs), "s"(off));
+    asm volatile("s_buffer_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(rs), "s"(off));
     return v;
-}
-__device__ __forceinline__ void sc_wait(u32x8 &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
-__device__ __forceinline__ void sc_wait(u32x8 &a, u32x8 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
-
-// A Window is the 32 bytes loaded for position q from byte offset (q & ~3) - 4: `before` = bytes [q-4, q), `at` = [q, q+4),
-// `after` = [q+4, q+12), `after2` = [q+12, q+20).  For q < 4 the load starts at offset 0 (an offset that wrapped below zero makes the
-// whole load read as zero: tools/sbuf.hip) and win_ready moves the dwords up by one, so that the accessors stay the same.
-struct Window { u32x8 d; uint32_t sh; };
-__device__ __forceinline__ Window win_load(const u32x4 &rs, uint32_t q)
-{
-    Window w;
-    const uint32_t q4 = q & ~3u;
-    w.d = sc_load32(rs, q4 ? q4 - 4u : 0u);
-    w.sh = (q & 3u) * 8u;
-    return w;
-}
-// after the wait: bring a window loaded for a position below 4 into the common layout (`before` then holds [0, q) in its top bytes)
-__device__ __forceinline__ void win_ready(Window &w, uint32_t q)
-{
-    if (q < 4) { // rare (the block's first probes, empty table slots): a real branch, not seven conditional moves on every window
-        asm volatile("" : "+s"(w.d));
-        w.d[7] = w.d[6]; w.d[6] = w.d[5]; w.d[5] = w.d[4]; w.d[4] = w.d[3]; w.d[3] = w.d[2]; w.d[2] = w.d[1]; w.d[1] = w.d[0]; w.d[0] = 0;
-    }
-}
-__device__ __forceinline__ uint32_t fun32(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
-__device__ __forceinline__ uint32_t win_before(const Window &w) { return fun32(w.d[0], w.d[1], w.sh); }
-__device__ __forceinline__ uint32_t win_at(const Window &w) { return fun32(w.d[1], w.d[2], w.sh); }
-__device__ __forceinline__ uint64_t win_after(const Window &w)
-{
-    return (uint64_t)fun32(w.d[2], w.d[3], w.sh) | ((uint64_t)fun32(w.d[3], w.d[4], w.sh) << 32);
-}
-__device__ __forceinline__ uint64_t win_after2(const Window &w)
-{
-    return (uint64_t)fun32(w.d[4], w.d[5], w.sh) | ((uint64_t)fun32(w.d[5], w.d[6], w.sh) << 32);
-}
-// 4 bytes at q - 2 of the window loaded for q (q >= 2)
-__device__ __forceinline__ uint32_t win_at_m2(const Window &w)
-{
-    // byte offset of q-2 inside the window: 2 + (q & 3) = 2..5
-    const uint32_t s2 = w.sh + 16u;
-    return s2 < 32u ? fun32(w.d[0], w.d[1], s2) : fun32(w.d[1], w.d[2], s2 - 32u);
 }
 
 __device__ __forceinline__ uint32_t hash13(uint32_t v) { return (v * 2654435761u) >> 19; }
@@ -168,193 +113,12 @@ __device__ __forceinline__ void copy_run(uint8_t *__restrict__ d, const uint8_t 
 
 } // namespace
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(CW_VT_COMPILER_VGPRS)))
-lz4_vtab_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
-                uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters, uint32_t min_queued,
-                uint32_t max_queued, uint32_t reserve)
-{
-    const uint32_t lane = threadIdx.x;
-    const uint32_t qcount = __builtin_amdgcn_readfirstlane(counters[1]);
-    if (qcount < min_queued || qcount >= max_queued) return; // the launch policy's regime test, on the device: the queue's length is only known here
-    const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals;
-
-    for (;;) {
-        // reserve > 0: other parsers pull from the same queue; stop pulling while `reserve` blocks are left (as the lane kernels do)
-        uint32_t qi = qcount;
-        if (lane == 0 && (!reserve || __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + reserve < qcount))
-            qi = atomicAdd(&counters[0], 1u);
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        if (qi >= qcount) break;
-        const size_t blk = queue[qi];
-        const uint8_t *g = src + blk * src_stride;
-        uint8_t *out = dst + blk * dst_stride;
-        u32x4 rs;
-        {
-            const uint64_t a = reinterpret_cast<uint64_t>(g);
-            rs.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
-            rs.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xFFFFu);
-            rs.z = n;           // num_records (bytes; stride 0): dwords beyond read as zero
-            rs.w = 0x00020000u; // raw buffer, 32-bit elements (gfx9 family)
-        }
-        vt_zero();
-
-        uint32_t anchor = 0, op = 0, ip = 1;
-        // a pending literal copy: bytes loaded one sequence ago, stored now (so the store never waits for its load)
-        uint32_t pend_val = 0, pend_pos = 0, pend_cnt = 0;
-
-        if (n >= kMFLimit + 1) {
-            Window wp = win_load(rs, ip);
-            sc_wait(wp.d);
-            win_ready(wp, ip);
-            for (;;) { // one sequence per iteration
-                // ---- search: probe ip, ip+1, ... with a stride that grows every 64 misses ----
-                uint32_t cur, cand;
-                Window wc;
-                bool found = false;
-                {
-                    uint32_t fip = ip, step = 1, nb = 64;
-                    for (;;) {
-                        cur = fip;
-                        fip += step;
-                        step = nb++ >> 6;
-                        if (fip > mflimit + 1) break;
-                        const uint32_t v = win_at(wp);
-                        cand = vt_exchange(hash13(v), cur);
-                        wc = win_load(rs, cand);
-                        Window wn = win_load(rs, fip);
-                        sc_wait(wc.d, wn.d);
-                        win_ready(wc, cand);
-                        win_ready(wn, fip);
-                        if (win_at(wc) == v) { found = true; break; }
-                        wp = wn;
-                    }
-                }
-                if (!found) break; // -> last literals
-                // ---- extend backwards over the pending literals (the windows hold 4 bytes; longer: the byte loop) ----
-                uint32_t back = 0;
-                {
-                    const uint32_t room = cur - anchor < cand ? cur - anchor : cand;
-                    if (room) {
-                        const uint32_t y = win_before(wp) ^ win_before(wc);
-                        back = y ? (uint32_t)__builtin_clz(y) >> 3 : 4u;
-                        if (back >= room) back = room;
-                        else if (back == 4) {
-                            for (;;) {
-                                const uint32_t j = back + lane + 1;
-                                const bool ok = j <= room && g[cur - j] == g[cand - j];
-                                const uint32_t cnt = ctz64(~__ballot(ok));
-                                back += cnt;
-                                if (cnt < 64) break;
-                            }
-                        }
-                    }
-                }
-                uint32_t lit = cur - back - anchor;
-                for (;;) { // next_match: entered again when the re-test after a match hits (no literals, no catch-up)
-                    // ---- forward extension from cur + 4 ----
-                    uint32_t mc;
-                    {
-                        const uint32_t lim = matchlimit - (cur + kMinMatch);
-                        const uint64_t x = win_after(wp) ^ win_after(wc);
-                        mc = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                        if (mc == 8 && lim > 8) {
-                            const uint64_t x2 = win_after2(wp) ^ win_after2(wc);
-                            mc += x2 ? (uint32_t)__builtin_ctzll(x2) >> 3 : 8u;
-                            if (mc == 16 && lim > 16) {
-                                for (;;) {
-                                    const uint32_t i = cur + kMinMatch + mc + lane;
-                                    const bool ok = i < matchlimit && g[i] == g[cand + kMinMatch + mc + lane];
-                                    const uint32_t cnt = ctz64(~__ballot(ok));
-                                    mc += cnt;
-                                    if (cnt < 64) break;
-                                }
-                            }
-                        }
-                        if (mc > lim) mc = lim;
-                    }
-                    const uint32_t mend = cur + kMinMatch + mc; // first byte after the match
-                    const uint32_t off = cur - cand;
-                    mc += back;
-                    // the next search's window now: the emission below does not wait for it
-                    const bool more = mend <= mflimit;
-                    Window wnext;
-                    if (more) wnext = win_load(rs, mend);
-
-                    // ---- emit: token, literals [anchor, anchor + lit), offset, match length ----
-                    if (pend_cnt) { // the previous sequence's literals (loaded an iteration ago)
-                        if (lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
-                        pend_cnt = 0;
-                    }
-                    const uint32_t tok_pos = op;
-                    uint32_t token;
-                    op += 1;
-                    if (lit >= 15) { token = 15u << 4; op += put_len(out + op, lit - 15, lane); }
-                    else token = lit << 4;
-                    if (lit) {
-                        if (lit <= 64) {
-                            pend_val = lane < lit ? g[anchor + lane] : 0u;
-                            pend_pos = op; pend_cnt = lit;
-                        } else {
-                            copy_run(out + op, g + anchor, lit, lane);
-                        }
-                        op += lit;
-                    }
-                    const uint32_t off_pos = op;
-                    op += 2;
-                    if (mc >= 15) { token += 15; op += put_len(out + op, mc - 15, lane); }
-                    else token += mc;
-                    if (lane < 3) { // token and the two offset bytes: three lanes, one store instruction
-                        const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
-                        const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
-                        out[where] = (uint8_t)what;
-                    }
-                    anchor = mend;
-                    ip = mend;
-                    if (!more) break;
-
-                    // ---- table: insert ip - 2, then the immediate re-test at ip ----
-                    sc_wait(wnext.d);
-                    wp = wnext;
-                    vt_exchange(hash13(win_at_m2(wp)), ip - 2);
-                    const uint32_t v = win_at(wp);
-                    cand = vt_exchange(hash13(v), ip);
-                    wc = win_load(rs, cand);
-                    Window wn = win_load(rs, ip + 1);
-                    sc_wait(wc.d, wn.d);
-                    win_ready(wc, cand);
-                    if (win_at(wc) == v) { cur = ip; back = 0; lit = 0; continue; }
-                    wp = wn;
-                    ip += 1;
-                    break;
-                }
-                if (anchor > mflimit) break; // end of parse: the remaining bytes are literals
-            }
-        }
-        if (pend_cnt && lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
-
-        // ---- last literals ----
-        {
-            const uint32_t run = n - anchor;
-            const uint32_t tok_pos = op;
-            op += 1;
-            if (run >= 15) {
-                if (lane == 0) out[tok_pos] = 15u << 4;
-                op += put_len(out + op, run - 15, lane);
-            } else if (lane == 0) {
-                out[tok_pos] = (uint8_t)(run << 4);
-            }
-            copy_run(out + op, g + anchor, run, lane);
-            op += run;
-        }
-        if (lane == 0) sizes[blk] = op;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Second generation: a batch of K items per memory round trip, the per-item arithmetic on the vector lanes.
+// Blocks up to 4 KiB (lz4_vtab2_kernel): a batch of K items per memory round trip, the per-item arithmetic on the vector lanes.
 //
-// The first kernel above is bound by SCALAR instruction issue (one scalar ALU per CU, shared by its four SIMDs): ~210 scalar
-// instructions per sequence on text, 16 wavefronts per CU, 18 GB/s; 4 / 8 / 12 / 16 wavefronts per CU give 9.7 / 14.1 / 16.1 / 18.4 GB/s.
+// The first form of this parser (all scalar, removed in round 3: 18 GB/s on text at 64 KiB, and it carried the split load/wait pattern
+// described above) was bound by SCALAR instruction issue (one scalar ALU per CU, shared by its four SIMDs): ~210 scalar instructions
+// per sequence on text; 4 / 8 / 12 / 16 wavefronts per CU gave 9.7 / 14.1 / 16.1 / 18.4 GB/s.
 // Here lane k of the wavefront owns item k of a batch -- after a match: insert(ip-2), re-test(ip), probe(ip+1), probe(ip+2); in a
 // continuing search: K probes -- and does everything that is per item on the VALU, all items at once: the item's position from the
 // skip schedule, its 4 + 8 + 4 bytes (one unaligned load each), its hash, and later the candidate's bytes, the 4-byte test and both
@@ -368,12 +132,16 @@ struct Saved { uint32_t r, l, w; };
 // entry h <- pos; returns the previous entry and what vt_restore needs to take the write back
 __device__ __forceinline__ uint32_t vt_exchange_s(uint32_t h, uint32_t pos, Saved &sv)
 {
-    const uint32_t r = h >> 7, l = (h >> 1) & 63u, sh = (h & 1u) << 4;
-    uint32_t w;
-    asm volatile("s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\t"
+    const uint32_t sh = (h & 1u) << 4;
+    uint32_t w, r, l;
+    // (register and lane are worked out INSIDE the statement: a lane select that a VALU instruction wrote -- a spilled value coming back
+    // through v_readlane_b32 -- needs four wait states in front of v_readlane_b32, and the compiler does not look into inline assembly)
+    asm volatile("s_lshr_b32 %1, %3, 7\n\t"
+                 "s_bfe_u32 %2, %3, 0x60001\n\t"
+                 "s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\t"
                  "v_readlane_b32 %0, " CW_VT_BASE ", %2\n\t"
                  "s_set_gpr_idx_off"
-                 : "=s"(w) : "s"(r), "s"(l) : CW_VT_CLOBBER);
+                 : "=&s"(w), "=&s"(r), "=&s"(l) : "s"(h) : "scc", CW_VT_CLOBBER);
     const uint32_t nw = (w & ~(0xFFFFu << sh)) | (pos << sh);
     asm volatile("s_lshl_b64 exec, 1, %2\n\t"
                  "s_set_gpr_idx_on %0, gpr_idx(DST)\n\t"
@@ -606,9 +374,10 @@ namespace {
 // entry h <- pos; returns the previous entry.  k_ffff: a VGPR holding 0xFFFF in every lane.
 __device__ __forceinline__ uint32_t vt3_exchange(uint32_t h, uint32_t pos, uint32_t k_ffff)
 {
-    const uint32_t r = h >> 7, l = (h >> 1) & 63u;
-    uint32_t old, w, t, ps, m, nw;
-    asm volatile("s_set_gpr_idx_on %[r], gpr_idx(SRC0)\n\t"
+    uint32_t old, w, t, ps, m, nw, r, l;
+    asm volatile("s_lshr_b32 %[r], %[h], 7\n\t"              // register and lane of the entry, on the scalar ALU and in here (see vt_exchange_s)
+                 "s_bfe_u32 %[l], %[h], 0x60001\n\t"
+                 "s_set_gpr_idx_on %[r], gpr_idx(SRC0)\n\t"
                  "v_readlane_b32 %[w], " CW_VT_BASE ", %[l]\n\t"
                  "s_set_gpr_idx_off\n\t"
                  "v_and_b32 %[t], 1, %[h]\n\t"
@@ -624,17 +393,18 @@ __device__ __forceinline__ uint32_t vt3_exchange(uint32_t h, uint32_t pos, uint3
                  "s_mov_b64 exec, -1\n\t"
                  "v_readfirstlane_b32 %[old], %[t]\n\t"
                  "s_and_b32 %[old], %[old], 0xffff"
-                 : [old] "=s"(old), [w] "=&s"(w), [t] "=&v"(t), [ps] "=&v"(ps), [m] "=&v"(m), [nw] "=&v"(nw)
-                 : [r] "s"(r), [l] "s"(l), [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
+                 : [old] "=&s"(old), [w] "=&s"(w), [t] "=&v"(t), [ps] "=&v"(ps), [m] "=&v"(m), [nw] "=&v"(nw), [r] "=&s"(r), [l] "=&s"(l)
+                 : [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
                  : "scc", CW_VT_CLOBBER);
     return old;
 }
 // entry h <- pos (the previous entry is of no interest: the insert in front of a re-test)
 __device__ __forceinline__ void vt3_put(uint32_t h, uint32_t pos, uint32_t k_ffff)
 {
-    const uint32_t r = h >> 7, l = (h >> 1) & 63u;
-    uint32_t w, t, ps, m, nw;
-    asm volatile("s_set_gpr_idx_on %[r], gpr_idx(SRC0)\n\t"
+    uint32_t w, t, ps, m, nw, r, l;
+    asm volatile("s_lshr_b32 %[r], %[h], 7\n\t"
+                 "s_bfe_u32 %[l], %[h], 0x60001\n\t"
+                 "s_set_gpr_idx_on %[r], gpr_idx(SRC0)\n\t"
                  "v_readlane_b32 %[w], " CW_VT_BASE ", %[l]\n\t"
                  "s_set_gpr_idx_off\n\t"
                  "v_and_b32 %[t], 1, %[h]\n\t"
@@ -647,8 +417,8 @@ __device__ __forceinline__ void vt3_put(uint32_t h, uint32_t pos, uint32_t k_fff
                  "v_mov_b32 " CW_VT_BASE ", %[nw]\n\t"
                  "s_set_gpr_idx_off\n\t"
                  "s_mov_b64 exec, -1"
-                 : [w] "=&s"(w), [t] "=&v"(t), [ps] "=&v"(ps), [m] "=&v"(m), [nw] "=&v"(nw)
-                 : [r] "s"(r), [l] "s"(l), [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
+                 : [w] "=&s"(w), [t] "=&v"(t), [ps] "=&v"(ps), [m] "=&v"(m), [nw] "=&v"(nw), [r] "=&s"(r), [l] "=&s"(l)
+                 : [h] "s"(h), [pos] "s"(pos), [kf] "v"(k_ffff)
                  : "scc", CW_VT_CLOBBER);
 }
 // The same two operations on a table in LDS (LDSTAB form of the third kernel, below): slot h of 8192 x u16 at byte address
@@ -669,22 +439,17 @@ __device__ __forceinline__ void lt3_put(uint32_t tab_lds, uint32_t h, uint32_t p
     asm volatile("ds_write_b16 %[a], %[p]" :: [a] "v"(tab_lds + 2u * h), [p] "v"(pos) : "memory");
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x2 sc_load8(const u32x4 &rs, uint32_t off)
+// (one statement per load group and its wait: see sc_load32_now)
+__device__ __forceinline__ void sc_load4x2_now(const u32x4 &rs, uint32_t off_a, uint32_t off_b, uint32_t &a, uint32_t &b)
 {
-    u32x2 v;
-    asm volatile("s_buffer_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(rs), "s"(off));
-    return v;
+    asm volatile("s_buffer_load_dword %0, %2, %3\n\ts_buffer_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(rs), "s"(off_a), "s"(off_b));
 }
-__device__ __forceinline__ uint32_t sc_load4(const u32x4 &rs, uint32_t off)
+__device__ __forceinline__ void sc_load32_8_now(const u32x4 &rs, uint32_t off_a, uint32_t off_b, u32x8 &a, u32x2 &b)
 {
-    uint32_t v;
-    asm volatile("s_buffer_load_dword %0, %1, %2" : "=s"(v) : "s"(rs), "s"(off));
-    return v;
+    asm volatile("s_buffer_load_dwordx8 %0, %2, %3\n\ts_buffer_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(rs), "s"(off_a), "s"(off_b));
 }
-__device__ __forceinline__ void sc_wait3(u32x8 &a, u32x8 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
-__device__ __forceinline__ void sc_wait3(u32x8 &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
-__device__ __forceinline__ void sc_wait3(u32x8 &a, u32x2 &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
-__device__ __forceinline__ void sc_wait3(uint32_t &a, uint32_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 // a wave-uniform value moved to a vector register: what is computed from it runs on the VALU
 __device__ __forceinline__ uint32_t to_v(uint32_t s)
 {
@@ -713,6 +478,86 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
     const uint32_t x0 = alo ^ blo, x1 = ahi ^ bhi;
     return x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;
 }
+
+// ---- emission in batches of 64 sequences ---------------------------------------------------------------------------------------
+// The parse only RECORDS a sequence (start of its literals, their number, match length - 4, offset) in lane `number of the sequence in
+// the batch` of four vector registers: five VALU instructions on the chain of a sequence instead of the ~80 that computing the token,
+// the length bytes, the output addresses and the literal copy for ONE sequence on a whole wavefront came to.  Every 64 sequences (and
+// at the end of the block) the batch is written out with the 64 lanes on 64 consecutive OUTPUT bytes: two prefix sums over the
+// sequences' encoded sizes give every sequence its place, a lane finds the sequence its byte belongs to by a binary search over the
+// prefix sums (six ds_bpermute: no LDS memory), works out which byte of the sequence that is -- token, literal length, literal,
+// offset, match length -- and stores it: coalesced byte stores, ~60 instructions per 64 bytes of output whatever the sequences look
+// like.  Literal runs longer than kFlatLit are left out of that byte space and copied 1 KiB per step afterwards.
+constexpr uint32_t kFlatLit = 96;
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_or0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); // lanes without a source lane (or in a masked row): 0
+}
+// inclusive prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    v += dpp_or0<0x111, 0xF>(v);
+    v += dpp_or0<0x112, 0xF>(v);
+    v += dpp_or0<0x114, 0xF>(v);
+    v += dpp_or0<0x118, 0xF>(v);
+    v += dpp_or0<0x142, 0xA>(v);
+    v += dpp_or0<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
+// LZ4 length field: number of continuation bytes of the value v (a literal count, or a match length - 4), and the k-th of them
+__device__ __forceinline__ uint32_t len_bytes(uint32_t v) { return v >= 15u ? 1u + (v - 15u) / 255u : 0u; }
+__device__ __forceinline__ uint32_t len_byte(uint32_t v, uint32_t nx, uint32_t k) { return k + 1u < nx ? 255u : v - 15u - 255u * (nx - 1u); }
+
+// writes sequences 0 .. nrec-1 of the batch (lane i: sequence i) at out + op0; returns the output position behind them
+__device__ __forceinline__ uint32_t emit_batch(uint8_t *__restrict__ out, const uint8_t *__restrict__ g, uint32_t op0, uint32_t nrec, uint32_t rec_a,
+                                               uint32_t rec_lit, uint32_t rec_ml, uint32_t rec_off, uint32_t lane)
+{
+    const bool live = lane < nrec;
+    const uint32_t lit = live ? rec_lit : 0u, ml = live ? rec_ml : 0u;
+    const uint32_t llx = len_bytes(lit), mlx = len_bytes(ml);
+    const uint32_t flat = lit > kFlatLit ? 0u : lit;
+    const uint32_t full = live ? 3u + llx + lit + mlx : 0u;  // token, literal length bytes, literals, offset (2), match length bytes
+    const uint32_t comp = live ? 3u + llx + flat + mlx : 0u; // the same without a long literal run: the byte space of the loop below
+    const uint32_t fend = wave_scan_add(full), cend = wave_scan_add(comp);
+    const uint32_t fstart = fend - full, cstart = cend - comp;
+    const uint32_t ctotal = __builtin_amdgcn_readlane(cend, 63), ftotal = __builtin_amdgcn_readlane(fend, 63);
+    // (two or four windows per step, their searches and loads interleaved, change nothing: 12.5 ms per 4,096 blocks of text either way --
+    // at 16 wavefronts per CU the other wavefronts fill the waits of this loop)
+    for (uint32_t base = 0; base < ctotal; base += 64) {
+        const uint32_t j = base + lane;
+        uint32_t sq = 0; // number of sequences that end at or before byte j = the sequence of byte j
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+            if (lane_get(cend, sq + step - 1u) <= j) sq += step;
+        const uint32_t q_cstart = lane_get(cstart, sq), q_fstart = lane_get(fstart, sq), q_a = lane_get(rec_a, sq), q_lit = lane_get(lit, sq),
+                       q_ml = lane_get(ml, sq), q_off = lane_get(rec_off, sq);
+        const uint32_t r = j - q_cstart;                      // byte r of the sequence (in the compacted space)
+        const uint32_t x = len_bytes(q_lit), y = len_bytes(q_ml), fl = q_lit > kFlatLit ? 0u : q_lit;
+        const uint32_t pre = 1u + x;                          // token + literal length bytes
+        if (j < ctotal) {
+            uint32_t byte, addr = q_fstart + r;
+            if (r == 0) {
+                byte = (min(q_lit, 15u) << 4) | min(q_ml, 15u);
+            } else if (r < pre) {
+                byte = len_byte(q_lit, x, r - 1u);
+            } else if (r < pre + fl) {
+                byte = g[q_a + (r - pre)];
+            } else {
+                const uint32_t r2 = r - pre - fl;
+                addr += q_lit - fl;
+                byte = r2 == 0 ? q_off : r2 == 1 ? q_off >> 8 : len_byte(q_ml, y, r2 - 2u);
+            }
+            out[op0 + addr] = (uint8_t)byte;
+        }
+    }
+    for (unsigned long long m = __ballot(live && lit > kFlatLit); m; m &= m - 1) { // long literal runs
+        const uint32_t q = (uint32_t)__builtin_ctzll(m);
+        copy_run(out + op0 + __builtin_amdgcn_readlane(fstart, q) + 1u + __builtin_amdgcn_readlane(llx, q), g + __builtin_amdgcn_readlane(rec_a, q),
+                 __builtin_amdgcn_readlane(lit, q), lane);
+    }
+    return op0 + ftotal;
+}
 } // namespace
 
 // (Tried and dropped: two probes per memory round trip -- while probe A's candidate is on its way, probe B is carried out as if A had
@@ -728,6 +573,24 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
 // (Tried and dropped: the candidate's bytes through the VECTOR memory path -- two bounds-checked buffer loads at a wave-uniform offset,
 // compared on the VALU -- on the theory that the scalar cache's few outstanding misses were the queue: text, 64 KiB, 8 Ki blocks
 // 20.8 -> 18.4 GB/s, 1,024 blocks 8.65 -> 7.26: the vector path's latency is simply longer.)
+// Diagnostic build only (-DCW_VSTAMP, tools/vtab_stamp.hip): where a sequence's cycles go.  A stamp is s_memtime; the differences are summed
+// per phase in scalar registers and added to g_vstamp once per block.  In the product build no stamp executes.
+#ifdef CW_VSTAMP
+__device__ unsigned long long g_vstamp[16];
+#define CW_VS_DECL uint32_t vs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vs_seq = 0, vs_probe = 0; unsigned long long vs_last = __builtin_amdgcn_s_memtime();
+#define CW_VS_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); vs_acc[i] += (uint32_t)(t_ - vs_last); vs_last = t_; } while (0)
+#define CW_VS_SEQ() (vs_seq++)
+#define CW_VS_PROBE() (vs_probe++)
+#define CW_VS_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_vstamp[i_], (unsigned long long)vs_acc[i_]); \
+                                            atomicAdd(&g_vstamp[14], (unsigned long long)vs_probe); atomicAdd(&g_vstamp[15], (unsigned long long)vs_seq); } } while (0)
+#else
+#define CW_VS_DECL
+#define CW_VS_AT(i) do { } while (0)
+#define CW_VS_SEQ() do { } while (0)
+#define CW_VS_PROBE() do { } while (0)
+#define CW_VS_FLUSH() do { } while (0)
+#endif
+
 // LDSTAB: the same scalar-thread parser with its table in LDS (16 KiB per wavefront, ten per CU) instead of in registers.  It takes
 // the place of the round-2 wavefront parser (lz4_parse_kernel<false>) beside the register form for blocks read from global memory: a
 // table operation is two LDS instructions at a wave-uniform address instead of an exchange over 64 lanes with its lane-order check and
@@ -772,27 +635,31 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             vt_zero();
         }
 
-        // wave-uniform state in vector registers: anchor, output position; a pending literal copy (per lane: the byte)
-        uint32_t anchor = to_v(0), op = to_v(0);
-        uint32_t pend_val = 0, pend_pos = to_v(0);
-        uint32_t pend_cnt = 0; // scalar
+        // anchor: wave-uniform, in a vector register.  The batch of recorded sequences: lane i of rec_* = sequence i, nrec of them; s_op = output
+        // position behind the last batch written
+        uint32_t anchor = to_v(0);
+        uint32_t rec_a = 0, rec_lit = 0, rec_ml = 0, rec_off = 0;
+        uint32_t nrec = 0, s_op = 0;
 
         if (n >= kMFLimit + 1) {
             // scalar state of the search: the probe position cur, its window wp = the 32 bytes from pb4 = cur & ~3 on
             uint32_t cur = 1, pb4 = 0;
-            u32x8 wp = sc_load32(rs, 0);
-            sc_wait3(wp);
+            u32x8 wp = sc_load32_now(rs, 0);
+            CW_VS_DECL
             // one probe: the table exchange, then the candidate's window and the next position's window in ONE round trip
 #define CW_VT3_PROBE(FIP)                                                                                                      \
             const uint32_t psh = (cur - pb4) * 8u;                                                                             \
             const uint32_t v = cut32(wp[0], wp[1], psh);                                                                       \
+            CW_VS_AT(0); CW_VS_PROBE();                                                                                        \
             const uint32_t cand = LDSTAB ? lt3_exchange(tab_lds, (v * 2654435761u) >> 19, cur)                                 \
                                          : vt3_exchange((v * 2654435761u) >> 19, cur, k_ffff);                                 \
+            CW_VS_AT(1);                                                                                                       \
             const uint32_t cb4 = cand & ~3u, csh = (cand & 3u) * 8u, fb4 = (FIP) & ~3u;                                         \
             CandWin wc;                                                                                                        \
             u32x8 wq;                                                                                                          \
             asm volatile("s_buffer_load_dwordx8 %0, %2, %3\n\ts_buffer_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"      \
                          : "=&s"(wc.s), "=&s"(wq) : "s"(rs), "s"(cb4), "s"(fb4));                                              \
+            CW_VS_AT(2);                                                                                                       \
             const bool hit = cut32(wc.s[0], wc.s[1], csh) == v;
 #define CW_VT3_ADVANCE(FIP)                                                                                                    \
             if (fb4 != pb4) { wp = wq; pb4 = fb4; }                                                                            \
@@ -817,6 +684,7 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                 if (!found) break; // -> last literals
                 bool first = true; // the match came out of the search (it may move back); false: out of the re-test after a match
                 for (;;) { // next_match
+                    CW_VS_AT(0); CW_VS_SEQ();
                     const uint32_t vcur = to_v(mcur), vcand = to_v(mcand);
                     uint32_t back = to_v(0);
                     if (first) {
@@ -824,8 +692,8 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                         const uint32_t room = min(vcur - anchor, vcand);
                         if (__builtin_amdgcn_readfirstlane(room) != 0) {
                             // the 4 bytes in front of both positions (an offset below zero reads as zero; room < 4 then anyway)
-                            uint32_t fp = sc_load4(rs, pb4 - 4u), fc = sc_load4(rs, mcb4 - 4u);
-                            sc_wait3(fp, fc);
+                            uint32_t fp, fc;
+                            sc_load4x2_now(rs, pb4 - 4u, mcb4 - 4u, fp, fc);
                             const uint32_t bp = __builtin_amdgcn_alignbit(to_v(wp[0]), to_v(fp), mpsh);
                             const uint32_t bc = __builtin_amdgcn_alignbit(mwc.template dw<0>(), to_v(fc), mcsh);
                             const uint32_t y = bp ^ bc;
@@ -845,6 +713,7 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                             }
                         }
                     }
+                    CW_VS_AT(3);
                     // forward: bytes 4..11 behind both positions, then 12..19, then the byte loop
                     uint32_t mc;
                     {
@@ -873,52 +742,32 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
                     }
                     const uint32_t vmend = vcur + kMinMatch + mc;     // first byte after the match
                     const uint32_t mend = __builtin_amdgcn_readfirstlane(vmend);
+                    CW_VS_AT(4);
                     const bool more = mend <= mflimit;
-                    // the windows of what follows the match, now: the emission below does not wait for them
-                    u32x8 wnext;
-                    u32x2 wins;
-                    const uint32_t nb4 = mend & ~3u, ib4 = (mend - 2u) & ~3u;
-                    if (more) { wnext = sc_load32(rs, nb4); wins = sc_load8(rs, ib4); }
 
-                    // ---- emit (VALU): token, literals [anchor, anchor + lit), offset, match length ----
-                    const uint32_t lit = vcur - back - anchor;
-                    const uint32_t off = vcur - vcand;
-                    const uint32_t mlen = mc + back;
-                    if (pend_cnt) { // the previous sequence's literals (loaded a sequence ago)
-                        if (lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
-                        pend_cnt = 0;
-                    }
-                    const uint32_t tok_pos = op;
-                    const uint32_t token = (min(lit, 15u) << 4) | min(mlen, 15u);
-                    op += 1;
-                    const uint32_t slit = __builtin_amdgcn_readfirstlane(lit);
-                    if (slit) {
-                        if (slit >= 15) op += put_len(out + __builtin_amdgcn_readfirstlane(op), slit - 15, lane);
-                        if (slit <= 64) {
-                            pend_val = lane < slit ? g[__builtin_amdgcn_readfirstlane(anchor) + lane] : 0u;
-                            pend_pos = op; pend_cnt = slit;
-                        } else {
-                            copy_run(out + __builtin_amdgcn_readfirstlane(op), g + __builtin_amdgcn_readfirstlane(anchor), slit, lane);
-                        }
-                        op += lit;
-                    }
-                    const uint32_t off_pos = op;
-                    op += 2;
-                    if (__builtin_amdgcn_readfirstlane((uint32_t)(mlen >= 15)))
-                        op += put_len(out + __builtin_amdgcn_readfirstlane(op), __builtin_amdgcn_readfirstlane(mlen) - 15, lane);
-                    if (lane < 3) { // token and the two offset bytes: three lanes, one store instruction
-                        const uint32_t where = lane == 0 ? tok_pos : off_pos + lane - 1;
-                        const uint32_t what = lane == 0 ? token : lane == 1 ? off : off >> 8;
-                        out[where] = (uint8_t)what;
+                    // ---- record the sequence: literals [anchor, anchor + lit), offset, match length - 4 ----
+                    {
+                        const bool mine = lane == nrec;
+                        rec_lit = mine ? vcur - back - anchor : rec_lit;
+                        rec_a = mine ? anchor : rec_a;
+                        rec_ml = mine ? mc + back : rec_ml;
+                        rec_off = mine ? vcur - vcand : rec_off;
+                        if (++nrec == 64) { s_op = emit_batch(out, g, s_op, 64, rec_a, rec_lit, rec_ml, rec_off, lane); nrec = 0; }
                     }
                     anchor = vmend;
+                    CW_VS_AT(5);
                     if (!more) { cur = mend; break; }
 
                     // ---- table: insert mend - 2, then the immediate re-test at mend ----
-                    sc_wait3(wnext, wins);
+                    u32x8 wnext; // the window at mend, and the 8 bytes around mend - 2
+                    u32x2 wins;
+                    const uint32_t nb4 = mend & ~3u;
+                    sc_load32_8_now(rs, nb4, (mend - 2u) & ~3u, wnext, wins);
+                    CW_VS_AT(6);
                     if constexpr (LDSTAB) lt3_put(tab_lds, (cut32(wins[0], wins[1], ((mend - 2u) & 3u) * 8u) * 2654435761u) >> 19, mend - 2u);
                     else vt3_put((cut32(wins[0], wins[1], ((mend - 2u) & 3u) * 8u) * 2654435761u) >> 19, mend - 2u, k_ffff);
                     wp = wnext; pb4 = nb4; cur = mend;
+                    CW_VS_AT(7);
                     {
                         const uint32_t fip = cur + 1;
                         CW_VT3_PROBE(fip)
@@ -931,10 +780,10 @@ lz4_vtab3_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
             }
 #undef CW_VT3_PROBE
 #undef CW_VT3_ADVANCE
+            CW_VS_FLUSH();
         }
         const uint32_t s_anchor = __builtin_amdgcn_readfirstlane(anchor);
-        uint32_t s_op = __builtin_amdgcn_readfirstlane(op);
-        if (pend_cnt && lane < pend_cnt) out[pend_pos + lane] = (uint8_t)pend_val;
+        if (nrec) s_op = emit_batch(out, g, s_op, nrec, rec_a, rec_lit, rec_ml, rec_off, lane);
 
         // ---- last literals ----
         {
@@ -959,21 +808,18 @@ hipError_t lz4_vtab_launch(const uint8_t *src, uint32_t n, size_t src_stride, si
                            const uint32_t *queue, uint32_t *counters, uint32_t min_queued, uint32_t max_queued, uint32_t reserve,
                            unsigned waves_per_cu, hipStream_t stream, const char **kernel_name)
 {
-    // CW_VTAB_GEN: 1 = the all-scalar kernel, 2 = batches of four items, 3 = the scalar chain with the VALU's help.  Default by measurement
-    // (GB/s alone, 16 wavefronts per CU): text, 64 KiB blocks, 8 Ki blocks 18.4 (1) / 13.7 (2) / 20.8 (3), 3,233 blocks 13.6 / 11.3 / 17.1;
-    // corpus, 4 KiB blocks 15.4-16.0 (1) against 17.8-17.9 (2)
+    // CW_VTAB_GEN: 2 = batches of four items (vector loads), 3 = the scalar chain with the VALU's help.  Default by measurement (GB/s alone,
+    // 16 wavefronts per CU; (1) = the all-scalar first form, removed): text, 64 KiB blocks, 8 Ki blocks 18.4 (1) / 13.7 (2) / 20.8 (3),
+    // 3,233 blocks 13.6 / 11.3 / 17.1; corpus, 4 KiB blocks 15.4-16.0 (1) against 17.8-17.9 (2)
     const char *gen_env = tune("CW_VTAB_GEN");
-    const int gen = gen_env ? atoi(gen_env) : n <= 4096 ? 2 : 3;
+    const int gen = gen_env && atoi(gen_env) == 2 ? 2 : gen_env && atoi(gen_env) == 3 ? 3 : n <= 4096 ? 2 : 3;
     if ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) return hipErrorInvalidValue; // the scalar loads are dword loads
     size_t grid = 256 * (size_t)(waves_per_cu ? waves_per_cu : 16);
     if (grid > nblocks) grid = nblocks;
     if (grid == 0) return hipSuccess;
-    if (kernel_name) *kernel_name = gen == 3 ? "cw::lz4_vtab3_kernel<false>" : gen == 1 ? "cw::lz4_vtab_kernel" : "cw::lz4_vtab2_kernel";
+    if (kernel_name) *kernel_name = gen == 3 ? "cw::lz4_vtab3_kernel<false>" : "cw::lz4_vtab2_kernel";
     if (gen == 3)
         hipLaunchKernelGGL(lz4_vtab3_kernel<false>, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
-                           min_queued, max_queued, reserve);
-    else if (gen == 1)
-        hipLaunchKernelGGL(lz4_vtab_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
                            min_queued, max_queued, reserve);
     else
         hipLaunchKernelGGL(lz4_vtab2_kernel, dim3((unsigned)grid), dim3(64), 0, stream, src, n, src_stride, dst, dst_stride, sizes, queue, counters,

@@ -130,8 +130,7 @@ def _sweep_data():
 LZ4_KNOBS = [
     dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0),                                                   # the LDS-table scalar-thread parser alone (blocks > 4 KiB)
     dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0, CW_LZ4_LTAB=0),                                    # round 2's wavefront parser alone
-    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=1, CW_LZ4_LANES=0),                                    # register-table parsers, each taking the whole queue
-    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0),
+    dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0),                                    # register-table parsers, each taking the whole queue
     dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_LZ4_LANES=0),
     dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_VTAB_WPC=1, CW_LZ4_LANES=0),
     dict(CW_LZ4_VTAB=2, CW_VTAB_GEN=3, CW_LZ4_LANES=0),                                    # beside the wavefront parser (the default regime)
@@ -180,7 +179,7 @@ def test_every_parser_variant_equals_the_oracle_in_one_process(cw, oracle, comp,
                     assert payload[i, : len(e)].tobytes() == e, (knobs, bs, i, names)
     joined = " | ".join(sorted(seen))
     if comp == "lz4":
-        for k in ("lz4_vtab_kernel", "lz4_vtab2_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
+        for k in ("lz4_vtab2_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
                   "lz4_lanes_ring_kernel<8>", "lz4_lanes_kernel<0>", "lz4_lanes_kernel<1>", "lz4_lanes_kernel<2>", "lz4_parse_fp_kernel<32>", "lz4_parse_kernel<true>", "lz4_parse_kernel<false>", "lz4_vtab3_kernel<true>", "lz4_vtab3_kernel<false>"):
             assert k in joined, (k, joined)
     else:
@@ -248,7 +247,7 @@ def test_register_table_parsers_on_block_sizes_that_are_not_multiples_of_four(cw
     s = torch.cuda.current_stream().cuda_stream
     dev = torch.from_numpy(raw).cuda()
     dstride = (cw.compress_bound("lz4", bs) + 15) // 16 * 16
-    for knobs in (dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=1, CW_LZ4_LANES=0), dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0),
+    for knobs in (dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=2, CW_LZ4_LANES=0), dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_VTAB_WPC=4, CW_LZ4_LANES=0),
                   dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_LZ4_LANES=0), dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0), dict()):
         dst = torch.zeros(nb * dstride, dtype=torch.uint8, device="cuda")
         sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
@@ -259,3 +258,34 @@ def test_register_table_parsers_on_block_sizes_that_are_not_multiples_of_four(cw
         hz, hd = sizes.cpu().numpy(), dst.view(nb, dstride).cpu().numpy()
         for i, e in enumerate(want):
             assert int(hz[i]) == len(e) and hd[i, : len(e)].tobytes() == e, (knobs, bs, i, names)
+
+
+def test_sequences_at_the_length_field_boundaries(cw, oracle):
+    """The scalar-thread parsers write their sequences out 64 at a time, a lane per output byte (emit_batch, lz4_vtab_kernel.hip): blocks built from
+    literal runs and matches whose lengths sit on the encoding's boundaries -- 14 / 15 / 16 (the nibble), 15 + 255 k +- 1 (length bytes), 96 / 97
+    (where a literal run leaves the per-byte loop), runs of many kilobytes -- in every order, so that batches mix all kinds."""
+    rng = np.random.default_rng(31)
+    lits = [0, 1, 2, 3, 13, 14, 15, 16, 17, 95, 96, 97, 98, 110, 254, 255, 256, 269, 270, 271, 272, 300, 524, 525, 526, 1000, 5000]
+    mats = [4, 5, 6, 17, 18, 19, 20, 21, 22, 272, 273, 274, 275, 276, 527, 528, 529, 530, 531, 2000, 9000]
+    bs, nb = 65536, 96
+    blocks = []
+    for b in range(nb):
+        out = bytearray(rng.integers(0, 256, 64, dtype=np.uint8).tobytes())
+        while len(out) < bs:
+            lit, m = int(rng.choice(lits)), int(rng.choice(mats))
+            if b % 3 == 2:                     # short sequences only: 64 to a batch, thousands of batches
+                lit, m = int(rng.integers(0, 18)), int(rng.integers(4, 24))
+            out += rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+            back = int(rng.integers(1, min(len(out), 65535) + 1))
+            for _ in range(m):                 # (byte by byte: the source may overlap what is being written)
+                out.append(out[-back])
+        blocks.append(bytes(out[:bs]))
+    want = [oracle.lz4_compress(b) for b in blocks]
+    data = b"".join(blocks)
+    for knobs in (dict(CW_LZ4_VTAB=1, CW_VTAB_GEN=3, CW_LZ4_LANES=0), dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0), dict()):
+        with cw.tuned(**knobs):
+            sizes, payload = cw.compress_blocks("lz4", data, bs)
+            names = cw.profile_kernels()["codec"]
+        assert "lz4_vtab3_kernel" in names, names
+        for i, e in enumerate(want):
+            assert int(sizes[i]) == len(e) and payload[i, : len(e)].tobytes() == e, (knobs, i, names)

@@ -15,7 +15,6 @@ run() { # tag, kernel filter, blocks, perf_probe args...
     rm -rf gpurun_out/pmc_${tag}_*
 }
 if [ "$1" = "vtab" ]; then # round 3: the register-table parsers, each taking the whole queue (CW_LZ4_VTAB=1), 16 wavefronts per CU
-    CW_LZ4_VTAB=1 CW_VTAB_GEN=1 CW_LZ4_LANES=0 run vtab_gen1 lz4_vtab_kernel   8192 --alg none --comp lz4 --bs 65536 --data text
     CW_LZ4_VTAB=1 CW_VTAB_GEN=3 CW_LZ4_LANES=0 run vtab_gen3 lz4_vtab3_kernel  8192 --alg none --comp lz4 --bs 65536 --data text
     CW_LZ4_VTAB=1 CW_VTAB_GEN=2 CW_LZ4_LANES=0 run vtab_gen2_4k lz4_vtab2_kernel 65536 --alg none --comp lz4 --bs 4096 --data text
     cat $O

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LZ4 parsers against each other on one input: throughput per launch-policy setting and, for every setting, every block's size and
+"""LZ4 (or, with --comp lzf, LZF) parsers against each other on one input: throughput per launch-policy setting and, for every setting, every block's size and
 payload digest against the oracle (not the contract bench; a profiling tool).
 
   gpurun -- 'python tools/vtab_probe.py --sizes 1024,3233,16384 > gpurun_out/vtab_probe.txt'
@@ -25,6 +25,7 @@ ap.add_argument("--bs", default="65536")
 ap.add_argument("--data", default="text", choices=["text", "corpus"])
 ap.add_argument("--settings", default="default;CW_LZ4_VTAB=1;CW_LZ4_VTAB=2")
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--comp", default="lz4", choices=["lz4", "lzf"])
 A = ap.parse_args()
 cw.init(0)
 O.build()
@@ -51,14 +52,14 @@ def rate(fn, nbytes, iters):
 settings = [x for x in A.settings.split(";") if x]
 for bs in [int(x) for x in A.bs.split(",")]:
     T = len(base) // bs
-    _, _, osz, opay = O.hash_and_compress(np.frombuffer(base, dtype=np.uint8), bs, O.HASH_NONE, O.COMP_LZ4, 8, want_payload=True)
+    _, _, osz, opay = O.hash_and_compress(np.frombuffer(base, dtype=np.uint8), bs, O.HASH_NONE, O.COMP_LZ4 if A.comp == "lz4" else O.COMP_LZF, 8, want_payload=True)
     odig = [hashlib.blake2b(opay[i, : int(osz[i])].tobytes(), digest_size=8).digest() for i in range(T)]
     print(f"# {A.data}: {T} x {bs} B blocks per period, ratio {T * bs / float(osz.sum()):.4f}", flush=True)
     for nb64 in [int(x) for x in A.sizes.split(",")]:
         nb = nb64 * (65536 // bs)
         t = (base * (nb * bs // len(base) + 1))[: nb * bs]
         src = torch.frombuffer(bytearray(t), dtype=torch.uint8).cuda()
-        stride = (cw.compress_bound("lz4", bs) + 15) // 16 * 16
+        stride = (cw.compress_bound(A.comp, bs) + 15) // 16 * 16
         dst = torch.zeros(nb * stride, dtype=torch.uint8, device="cuda")
         sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
         want_sz = torch.from_numpy(osz.astype(np.int32)).cuda().repeat((nb + T - 1) // T)[:nb]
@@ -67,7 +68,7 @@ for bs in [int(x) for x in A.bs.split(",")]:
             with cw.tuned(**knobs):
                 dst.zero_()
                 sizes.zero_()
-                r = rate(lambda: cw.dev_compress("lz4", src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s), nb * bs,
+                r = rate(lambda: cw.dev_compress(A.comp, src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s), nb * bs,
                          3 if nb64 >= 16384 else 8)
                 names = cw.profile_kernels()["codec"]
             verdict = "unchecked"
