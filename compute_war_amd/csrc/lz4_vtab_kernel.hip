@@ -23,17 +23,18 @@
 
 #include "cw_device.h"
 #include "lz_device.h"
+#include "scalar_thread.h"
 
 #pragma clang diagnostic ignored "-Winline-asm" // "clobber list contains reserved registers": that is the point (see below)
 
 namespace cw {
 
+using namespace st;
+
 namespace {
 
 constexpr uint32_t kMinMatch = 4, kLastLiterals = 5, kMFLimit = 12;
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 // ---- the table: v[64..127] -------------------------------------------------------------------------------------------
 // amdgpu_num_vgpr(32): on gfx90a and later the attribute counts half of the unified file, so the compiler allocates v0..v63 (it cannot
@@ -53,22 +54,6 @@ __device__ __forceinline__ void vt_zero()
     asm volatile(".irp r,64,65,66,67,68,69,70,71,72,73,74,75,76,77,78,79,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95,96,97,98,99,1"
                  "00,101,102,103,104,105,106,107,108,109,110,111,112,113,114,115,116,117,118,119,120,121,122,123,124,125,126,127\n\tv_mov_b32 v\\r, 0\n\t.endr"
                  ::: CW_VT_CLOBBER);
-}
-
-// ---- the input through the scalar cache -------------------------------------------------------------------------------
-// s_buffer_load_*: bytes at byte offset `off` (a multiple of 4) of the block described by rs; dwords outside [0, num_records) read as
-// zero (an offset that wrapped below zero makes the WHOLE load read as zero: tools/sbuf.hip).
-// RULE: a scalar load and the s_waitcnt that covers it are ONE asm statement.  The compiler does not know that the destination
-// registers of an s_buffer_load in inline assembly are still in flight behind the statement: with the load in one statement and the
-// wait in a later one (as this file had it, to run the emission of a sequence under the next windows' latency) it is free to copy or
-// spill those registers in between -- and did, in the -DCW_VSTAMP build of the day: an `s_mov_b64` of the two dwords in front of the
-// emission read them before they had arrived once in ~40,000 sequences, and half of all blocks came out a few bytes wrong.  The
-// product build of the same source happened to have no such copy and passed every test.
-__device__ __forceinline__ u32x8 sc_load32_now(const u32x4 &rs, uint32_t off)
-{
-    u32x8 v;
-    asm volatile("s_buffer_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(rs), "s"(off));
-    return v;
 }
 
 __device__ __forceinline__ uint32_t hash13(uint32_t v) { return (v * 2654435761u) >> 19; }
@@ -438,47 +423,12 @@ __device__ __forceinline__ void lt3_put(uint32_t tab_lds, uint32_t h, uint32_t p
 {
     asm volatile("ds_write_b16 %[a], %[p]" :: [a] "v"(tab_lds + 2u * h), [p] "v"(pos) : "memory");
 }
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-// (one statement per load group and its wait: see sc_load32_now)
-__device__ __forceinline__ void sc_load4x2_now(const u32x4 &rs, uint32_t off_a, uint32_t off_b, uint32_t &a, uint32_t &b)
-{
-    asm volatile("s_buffer_load_dword %0, %2, %3\n\ts_buffer_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(a), "=&s"(b) : "s"(rs), "s"(off_a), "s"(off_b));
-}
-__device__ __forceinline__ void sc_load32_8_now(const u32x4 &rs, uint32_t off_a, uint32_t off_b, u32x8 &a, u32x2 &b)
-{
-    asm volatile("s_buffer_load_dwordx8 %0, %2, %3\n\ts_buffer_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(a), "=&s"(b) : "s"(rs), "s"(off_a), "s"(off_b));
-}
-// a wave-uniform value moved to a vector register: what is computed from it runs on the VALU
-__device__ __forceinline__ uint32_t to_v(uint32_t s)
-{
-    uint32_t v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
-    return v;
-}
-// 4 bytes at bit offset sh (0, 8, 16 or 24) of the 8 bytes lo | hi << 32, on the scalar unit (lo, hi: an aligned register pair)
-__device__ __forceinline__ uint32_t cut32(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
-// 8 bytes at bit offset sh of the 12 bytes d1 | d2 << 32 | d3 << 64, on the VALU (wave-uniform vector registers)
-__device__ __forceinline__ void cut64_v(uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sh, uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t v1 = to_v(d1), v2 = to_v(d2), v3 = to_v(d3);
-    lo = __builtin_amdgcn_alignbit(v2, v1, sh);
-    hi = __builtin_amdgcn_alignbit(v3, v2, sh);
-}
 // a candidate's window: 32 bytes in scalar registers
 struct CandWin {
     u32x8 s;
     template <int I> __device__ __forceinline__ uint32_t dw() const { return to_v(s[I]); }
     template <int I> __device__ __forceinline__ void cut64(uint32_t sh, uint32_t &lo, uint32_t &hi) const { cut64_v(s[I], s[I + 1], s[I + 2], sh, lo, hi); }
 };
-// number of equal low bytes of two 8-byte values (0..8), on the VALU
-__device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi)
-{
-    const uint32_t x0 = alo ^ blo, x1 = ahi ^ bhi;
-    return x0 ? (uint32_t)__builtin_ctz(x0) >> 3 : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;
-}
-
 // ---- emission in batches of 64 sequences ---------------------------------------------------------------------------------------
 // The parse only RECORDS a sequence (start of its literals, their number, match length - 4, offset) in lane `number of the sequence in
 // the batch` of four vector registers: five VALU instructions on the chain of a sequence instead of the ~80 that computing the token,
@@ -489,22 +439,6 @@ __device__ __forceinline__ uint32_t equal_bytes_v(uint32_t alo, uint32_t ahi, ui
 // offset, match length -- and stores it: coalesced byte stores, ~60 instructions per 64 bytes of output whatever the sequences look
 // like.  Literal runs longer than kFlatLit are left out of that byte space and copied 1 KiB per step afterwards.
 constexpr uint32_t kFlatLit = 96;
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_or0(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); // lanes without a source lane (or in a masked row): 0
-}
-// inclusive prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
-{
-    v += dpp_or0<0x111, 0xF>(v);
-    v += dpp_or0<0x112, 0xF>(v);
-    v += dpp_or0<0x114, 0xF>(v);
-    v += dpp_or0<0x118, 0xF>(v);
-    v += dpp_or0<0x142, 0xA>(v);
-    v += dpp_or0<0x143, 0xC>(v);
-    return v;
-}
-__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
 // LZ4 length field: number of continuation bytes of the value v (a literal count, or a match length - 4), and the k-th of them
 __device__ __forceinline__ uint32_t len_bytes(uint32_t v) { return v >= 15u ? 1u + (v - 15u) / 255u : 0u; }
 __device__ __forceinline__ uint32_t len_byte(uint32_t v, uint32_t nx, uint32_t k) { return k + 1u < nx ? 255u : v - 15u - 255u * (nx - 1u); }

@@ -22,7 +22,8 @@
 //   lzf_links_kernel + lzf_chain_kernel   (everything else from 16 bytes on) per-position "previous position with my slot"
 //                      (128 KiB table, throughput bound), then the parse on link chains + skip flags with no table: blocks
 //                      <= 4 KiB with links and block in LDS (12.3 KiB, 13 blocks per CU), larger ones with only the skip
-//                      bits in LDS;
+//                      bits in LDS -- and, since round 3, parsed by lzf_sthread_kernel: the same algorithm with the wavefront
+//                      run as one scalar thread (the wavefront-wide lzf_chain_kernel<true> is kept as CW_LZF_STHREAD=0);
 //   lzf_parse_kernel   (blocks < 16 bytes; CW_LZF_MODE=table) 128 KiB table in LDS, one block per CU; table operation of a
 //                      batch = one ds_mskor_rtn_b32 exchange, lanes in ascending order, verified per batch;
 //   redo:              lzf_blocks_kernel, the first-generation parser (write/read-back collision detection, batch
@@ -39,6 +40,7 @@
 
 #include "cw_device.h"
 #include "lz_device.h"
+#include "scalar_thread.h"
 
 namespace cw {
 
@@ -830,6 +832,273 @@ lzf_chain_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Scalar-thread chain parser (round 3; blocks > 4 KiB): lzf_chain_kernel<true>'s algorithm -- links from lzf_links_kernel, one skip bit per
+// position in LDS, no table -- with the wavefront run as ONE scalar thread, like the LZ4 parsers of lz4_vtab_kernel.hip.
+// The wavefront-wide chain kernel speculates on 8..64 positions per step, but on compressible data a match ends the step after two
+// or three of them, and each step is a chain of VECTOR memory round trips (link, skip word, candidate bytes: 56 ms per 8 Ki blocks of
+// text, 9.5 GB/s).  Here a position is ~20 scalar instructions, and what it needs from memory comes in ONE round trip through the
+// scalar cache and the LDS together: the skip word of the candidate, the candidate's own link (the next step of the chain, should
+// it turn out to be skipped) and the 32 bytes around it -- plus, every fourth position, the next 32 bytes of the block and the next four
+// links.  A position whose link is empty or out of reach costs no memory access at all.  Sequences are recorded and written out 64 at a
+// time, a lane per output byte (as lz4_vtab_kernel.hip's emit_batch); the parser's overflow checks run on a scalar copy of liblzf's
+// (op, lit) arithmetic, so "returns 0" is exact.  8 KiB of LDS per 64 KiB block: 20 single-wavefront workgroups per CU.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+using namespace st;
+constexpr uint32_t kNoMatch = 0xFFFFFFFFu; // rec_m of the block's last literals
+
+// bytes of a literal run of L bytes in the stream (a control byte per 32), of a match with l2 = length - 2
+__device__ __forceinline__ uint32_t lzf_lit_bytes(uint32_t L) { return L + ((L + 31u) >> 5); }
+
+// writes sequences 0 .. nrec-1 of the batch (lane i: literals [a, a + L), then the match m = l2 | off << 16, or kNoMatch) at out + op0;
+// returns the output position behind them
+__device__ __forceinline__ uint32_t lzf_emit_batch(uint8_t *__restrict__ out, const uint8_t *__restrict__ g, uint32_t op0, uint32_t nrec, uint32_t rec_a,
+                                                   uint32_t rec_L, uint32_t rec_m, uint32_t lane)
+{
+    const bool live = lane < nrec;
+    const uint32_t L = live ? rec_L : 0u;
+    const uint32_t mb = !live || rec_m == kNoMatch ? 0u : (rec_m & 0xFFFFu) < 7u ? 2u : 3u;
+    const uint32_t full = lzf_lit_bytes(L) + mb;
+    const uint32_t fend = wave_scan_add(full), fstart = fend - full;
+    const uint32_t total = __builtin_amdgcn_readlane(fend, 63);
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t j = base + lane;
+        uint32_t sq = 0; // number of sequences that end at or before byte j = the sequence of byte j
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+            if (lane_get(fend, sq + step - 1u) <= j) sq += step;
+        const uint32_t q_fstart = lane_get(fstart, sq), q_a = lane_get(rec_a, sq), q_L = lane_get(L, sq), q_m = lane_get(rec_m, sq);
+        const uint32_t r = j - q_fstart, lb = lzf_lit_bytes(q_L);
+        if (j < total) {
+            uint32_t byte;
+            if (r < lb) { // run c of the literals: a control byte, then up to 32 bytes
+                const uint32_t c = r / 33u, k = r - 33u * c;
+                byte = k == 0 ? min(32u, q_L - 32u * c) - 1u : (uint32_t)g[q_a + 32u * c + k - 1u];
+            } else {
+                const uint32_t r2 = r - lb, l2 = q_m & 0xFFFFu, off = q_m >> 16;
+                if (l2 < 7) byte = r2 == 0 ? (off >> 8) + (l2 << 5) : off;
+                else byte = r2 == 0 ? (off >> 8) + (7u << 5) : r2 == 1 ? l2 - 7u : off;
+            }
+            out[op0 + j] = (uint8_t)byte;
+        }
+    }
+    return op0 + total;
+}
+
+// One step of a position's chain, ONE wait: the skip word of `cur` (LDS), the dword of links that holds cur's own link, the 32 bytes
+// from cur & ~3 on; NEXT: also the block's next 32 bytes and next four links (the position in hand is the last of its dword).
+// (Loads and wait in one statement: scalar_thread.h.)
+template <bool NEXT>
+__device__ __forceinline__ void lzf_step_loads(uint32_t skip_addr, const u32x4 &rs, const u32x4 &rl, uint32_t coff, uint32_t loff, uint32_t noff,
+                                               uint32_t nloff, uint32_t &skipword, uint32_t &lnk, u32x8 &wc, u32x8 &wq, u32x2 &lq)
+{
+    uint32_t sv;
+    if constexpr (NEXT)
+        asm volatile("ds_read_b32 %[sv], %[sa]\n\t"
+                     "s_buffer_load_dword %[lnk], %[rl], %[loff]\n\t"
+                     "s_buffer_load_dwordx8 %[wc], %[rs], %[coff]\n\t"
+                     "s_buffer_load_dwordx8 %[wq], %[rs], %[noff]\n\t"
+                     "s_buffer_load_dwordx2 %[lq], %[rl], %[nloff]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %[sw], %[sv]"
+                     : [sv] "=&v"(sv), [lnk] "=&s"(lnk), [wc] "=&s"(wc), [wq] "=&s"(wq), [lq] "=&s"(lq), [sw] "=&s"(skipword)
+                     : [sa] "v"(skip_addr), [rs] "s"(rs), [rl] "s"(rl), [coff] "s"(coff), [loff] "s"(loff), [noff] "s"(noff), [nloff] "s"(nloff)
+                     : "memory");
+    else
+        asm volatile("ds_read_b32 %[sv], %[sa]\n\t"
+                     "s_buffer_load_dword %[lnk], %[rl], %[loff]\n\t"
+                     "s_buffer_load_dwordx8 %[wc], %[rs], %[coff]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %[sw], %[sv]"
+                     : [sv] "=&v"(sv), [lnk] "=&s"(lnk), [wc] "=&s"(wc), [sw] "=&s"(skipword)
+                     : [sa] "v"(skip_addr), [rs] "s"(rs), [rl] "s"(rl), [coff] "s"(coff), [loff] "s"(loff)
+                     : "memory");
+}
+// the block's 32 bytes from byte offset noff on and the four links from byte offset nloff on
+__device__ __forceinline__ void lzf_next_loads(const u32x4 &rs, const u32x4 &rl, uint32_t noff, uint32_t nloff, u32x8 &wq, u32x2 &lq)
+{
+    asm volatile("s_buffer_load_dwordx8 %[wq], %[rs], %[noff]\n\t"
+                 "s_buffer_load_dwordx2 %[lq], %[rl], %[nloff]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [wq] "=&s"(wq), [lq] "=&s"(lq) : [rs] "s"(rs), [rl] "s"(rl), [noff] "s"(noff), [nloff] "s"(nloff));
+}
+} // namespace
+
+__global__ void __launch_bounds__(64)
+lzf_sthread_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, size_t nblocks, uint8_t *__restrict__ dst, size_t dst_stride,
+                   uint32_t *__restrict__ sizes, uint16_t *__restrict__ links, uint32_t n2, uint32_t *__restrict__ counter, LaneShare share,
+                   BlockList list)
+{
+    if (list.queue) {
+        const uint32_t cnt = *list.count;
+        if (list.first >= cnt) return;
+        if (nblocks > cnt - list.first) nblocks = cnt - list.first;
+    }
+    uint32_t taken = 0;
+    if (share.ctr) { // (the round is claimed: its links kernel ran and published)
+        taken = share_round_taken(share, nblocks, false);
+        if (taken == kShareGaveUp || share.round_first >= share.total - taken) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *skipmap = reinterpret_cast<uint32_t *>(smem); // one bit per position
+    const uint32_t map_lds = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cap = n - 1;
+
+    for (;;) {
+        // blocks are handed out dynamically: their parse times differ by an order of magnitude
+        uint32_t drawn = 0;
+        if (lane == 0) drawn = atomicAdd(counter, 1u);
+        const size_t blk = __builtin_amdgcn_readfirstlane(drawn);
+        if (blk >= nblocks) break;
+        if (lanes_took(share, taken, blk)) continue;                       // a lane parses (or parsed) it
+        const size_t gb = list.at(blk);
+        if (__builtin_amdgcn_readfirstlane(sizes[gb]) == kRedo) continue; // links not valid: lzf_blocks_kernel parses it
+        const uint8_t *g = src + gb * src_stride;
+        uint8_t *out = dst + gb * dst_stride;
+        uint16_t *lk = links + blk * (size_t)n2;
+        const u32x4 rs = sc_descriptor(g, n), rl = sc_descriptor(lk, n2 * 2u);
+        for (uint32_t i = lane; i < n2 / 32; i += 64) skipmap[i] = 0;
+        asm volatile("" ::: "memory");
+
+        // the parse: liblzf's loop (oracle/lzf_oracle.c), every value wave-uniform.  (op, lit): liblzf's output position and open literal
+        // run, kept for its overflow checks only; the bytes are written by lzf_emit_batch from the records
+        uint32_t ip = 0, anchor = 0, op = 1, lit = 0;
+        uint32_t rec_a = 0, rec_L = 0, rec_m = 0, nrec = 0, s_op = 0;
+        bool fail = false;
+        u32x8 wp;   // the 32 bytes from ip & ~3 on
+        u32x2 lwin; // the links of positions ip & ~3 .. + 3
+        lzf_next_loads(rs, rl, 0, 0, wp, lwin);
+        while (ip + 2 < n) {
+            const uint32_t b = ip & 3u;
+            const uint32_t v3 = cut32(wp[0], wp[1], b * 8u) & 0xFFFFFFu;
+            uint32_t cur = (uint32_t)((((uint64_t)lwin[1] << 32) | lwin[0]) >> (b * 16u)) & 0xFFFFu;
+            const bool cross = b == 3u; // the next position starts a new dword of the block and a new group of four links
+            const uint32_t nip = ip + 1u;
+            u32x8 wq, wc;
+            u32x2 lq;
+            bool have_next = false, match = false;
+            if (cur != 0 && ip - cur - 1u < kMaxOff) {
+                // the reference the serial parser would read: the first position on the link chain that was inserted (not skipped as the
+                // inside of a match), as long as it is within reach -- a chain only moves further away.  Path compression as in
+                // lzf_chain_kernel: the first skipped position of a walk gets the walk's end as its link.
+                uint32_t first_skipped = 0;
+                for (;;) {
+                    uint32_t skipword, lnk;
+                    const uint32_t sa = to_v(map_lds + (cur >> 5) * 4u);
+                    if (cross && !have_next) {
+                        lzf_step_loads<true>(sa, rs, rl, cur & ~3u, (cur * 2u) & ~3u, nip, nip * 2u, skipword, lnk, wc, wq, lq);
+                        have_next = true;
+                    } else {
+                        lzf_step_loads<false>(sa, rs, rl, cur & ~3u, (cur * 2u) & ~3u, 0, 0, skipword, lnk, wc, wq, lq);
+                    }
+                    if (!((skipword >> (cur & 31u)) & 1u)) {
+                        match = (cut32(wc[0], wc[1], (cur & 3u) * 8u) & 0xFFFFFFu) == v3;
+                        break;
+                    }
+                    if (!first_skipped) first_skipped = cur;
+                    cur = (lnk >> ((cur & 1u) * 16u)) & 0xFFFFu;
+                    if (cur == 0 || ip - cur - 1u >= kMaxOff) break; // the chain has ended or left the window
+                }
+                if (first_skipped && lane == 0) lk[first_skipped] = (uint16_t)cur;
+            }
+            if (match) {
+                // ---- length: equal bytes from the two windows (24 of them), then 64 at a time ----
+                const uint32_t psh = b * 8u, csh = (cur & 3u) * 8u;
+                uint32_t plo, phi, clo, chi;
+                cut64_v(wp[0], wp[1], wp[2], psh, plo, phi);
+                cut64_v(wc[0], wc[1], wc[2], csh, clo, chi);
+                uint32_t T = equal_bytes_v(plo, phi, clo, chi); // >= 3
+                if (__builtin_amdgcn_readfirstlane((uint32_t)(T == 8))) {
+                    cut64_v(wp[2], wp[3], wp[4], psh, plo, phi);
+                    cut64_v(wc[2], wc[3], wc[4], csh, clo, chi);
+                    T = 8u + equal_bytes_v(plo, phi, clo, chi);
+                    if (__builtin_amdgcn_readfirstlane((uint32_t)(T == 16))) {
+                        cut64_v(wp[4], wp[5], wp[6], psh, plo, phi);
+                        cut64_v(wc[4], wc[5], wc[6], csh, clo, chi);
+                        T = 16u + equal_bytes_v(plo, phi, clo, chi);
+                        if (__builtin_amdgcn_readfirstlane((uint32_t)(T == 24))) {
+                            uint32_t t = 24;
+                            for (;;) {
+                                const uint32_t i = t + lane;
+                                const bool ok = ip + i < n && i < kMaxRef + 2 && g[cur + i] == g[ip + i];
+                                const uint32_t cnt = ctz64(~__ballot(ok));
+                                t += cnt;
+                                if (cnt < 64) break;
+                            }
+                            T = t;
+                        }
+                    }
+                }
+                uint32_t eq = __builtin_amdgcn_readfirstlane(T) - 3u;
+                {
+                    const uint32_t room = (n - ip < kMaxRef + 2 ? n - ip : kMaxRef + 2) - 3u; // (windows read zeros beyond the block)
+                    if (eq > room) eq = room;
+                }
+                uint32_t maxlen = n - ip - 2u, len;
+                if (maxlen > kMaxRef) maxlen = kMaxRef;
+                if (maxlen > 16) { // liblzf's sixteen unrolled, unbounded compares
+                    if (eq < 16) len = 3u + eq;
+                    else { len = 3u + eq < maxlen ? 3u + eq : maxlen; if (len < 19) len = 19; }
+                } else {
+                    len = 3u + eq < maxlen ? 3u + eq : maxlen;
+                    if (len < 3) len = 3;
+                }
+                if (op - (lit == 0) + 4u >= cap) { fail = true; break; }
+                if (lit == 0) op -= 1;
+                const uint32_t l2 = len - 2u, off = ip - cur - 1u;
+                op += l2 < 7 ? 2u : 3u;
+                lit = 0; op += 1;
+                {
+                    const bool mine = lane == nrec;
+                    rec_a = mine ? anchor : rec_a;
+                    rec_L = mine ? ip - anchor : rec_L;
+                    rec_m = mine ? l2 | (off << 16) : rec_m;
+                    if (++nrec == 64) { s_op = lzf_emit_batch(out, g, s_op, 64, rec_a, rec_L, rec_m, lane); nrec = 0; }
+                }
+                // the inside of the match is never inserted (VERY_FAST re-inserts only its last two positions): positions [ip + 1, ip + len - 2)
+                if (len > 3) {
+                    const uint32_t first = ip + 1u, last = ip + len - 2u; // [first, last): up to 261 bits, ten words at most
+                    const uint32_t w = (first >> 5) + lane;
+                    const uint32_t lo = max(first, w * 32u), hi = min(last, w * 32u + 32u);
+                    if (lane < 10 && lo < hi) {
+                        const uint32_t bits = hi - lo;
+                        atomicOr(&skipmap[w], (bits == 32 ? 0xFFFFFFFFu : (1u << bits) - 1u) << (lo & 31u));
+                    }
+                }
+                asm volatile("" ::: "memory");
+                ip += len;
+                anchor = ip;
+                if (ip + 2 >= n) break;
+                lzf_next_loads(rs, rl, ip & ~3u, (ip * 2u) & ~7u, wp, lwin);
+                continue;
+            }
+            // ---- a literal ----
+            if (op >= cap) { fail = true; break; }
+            lit += 1; op += 1;
+            if (lit == kMaxLit) { lit = 0; op += 1; }
+            if (cross) {
+                if (!have_next) lzf_next_loads(rs, rl, nip, nip * 2u, wq, lq);
+                wp = wq; lwin = lq;
+            }
+            ip = nip;
+        }
+        if (!fail && op + 3 > cap) fail = true;
+        if (!fail) {
+            if (anchor < n) {
+                const bool mine = lane == nrec;
+                rec_a = mine ? anchor : rec_a;
+                rec_L = mine ? n - anchor : rec_L;
+                rec_m = mine ? kNoMatch : rec_m;
+                nrec += 1;
+            }
+            if (nrec) s_op = lzf_emit_batch(out, g, s_op, nrec, rec_a, rec_L, rec_m, lane);
+        }
+        if (lane == 0) sizes[gb] = fail ? 0u : s_op;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Lane-per-block parser for large batches of blocks that do not fit the LDS-resident scheme (> 4 KiB): the counterpart
 // of lz4_lanes_kernel (lz4_kernel.hip has the reasoning).  A lane runs liblzf's loop as it stands -- one position per
 // iteration: hash the next three bytes, exchange the table slot, test the reference, emit a literal or a match -- with its
@@ -844,6 +1113,7 @@ constexpr uint32_t kLzfLaneMinSmall = 28672;  // blocks <= 4 KiB: lanes beside t
 constexpr size_t kLzfBesideRound = 16384;     // ... in rounds of 16 Ki blocks, the last 16 Ki unclaimed blocks left to the rounds.  4 KiB blocks, text /
                                               // 50 % noise / noise, GB/s -- 1 Mi blocks: rounds of 8 Ki 29.8 / 24.7 / 52.9, 16 Ki 33.1 / 29.0 / 57.7,
                                               // 32 Ki 32.6 / 30.9 / 59.2; 96 Ki blocks: 25.6 / 36.3 / 50.5, 26.2 / 39.3 / 53.6, 23.1 / 36.4 / 55.0
+constexpr size_t kLzfBigBesideMin = 98304, kLzfBigBesideRound = 8192; // blocks > 16 KiB: lanes beside the rounds from 96 Ki blocks on, rounds of 8 Ki blocks, as many left to the rounds
 constexpr uint32_t kLzfBesideReserve = 16384, kLzfBesideReserveFew = 8192; // blocks left to the rounds; below 48 Ki blocks (32 Ki blocks: 16.1 against 13.2 GB/s with 16 Ki)
 
 // 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
@@ -1127,8 +1397,17 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const size_t lane_min = lanes_env ? (size_t)atoi(lanes_env) : (big ? (n > 8192 ? kLzfLaneMinBlocks : 18432u) : kLzfLaneMinSmall);
         const char *cc_env = tune("CW_LANES_CONCURRENT");
         bool use_lanes = lane_min && nblocks >= lane_min;
-        bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big);
-        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? kLzfBesideRound : ws_bytes / (2 * (size_t)n2);
+        // blocks > 4 KiB: the scalar-thread form of the chain parser (CW_LZF_STHREAD=0: the wavefront-wide one); needs dword-aligned blocks
+        const char *st_env = tune("CW_LZF_STHREAD");
+        const char *stw_env = tune("CW_LZF_ST_WPC");
+        const size_t st_wpc = stw_env && atoi(stw_env) > 0 ? (size_t)atoi(stw_env) : 20;
+        const bool sthread = big && (st_env ? st_env[0] != '0' : true) && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) == 0;
+        // lanes BESIDE the rounds: blocks <= 4 KiB always; larger blocks from kLzfBigBesideMin blocks on, and only with the scalar-thread
+        // parser in the rounds (corpus, 64 KiB, lanes alone -> beside: 64 Ki blocks 27.3-28.7 -> 28.4, 128 Ki 27.3 -> 30.3, 256 Ki 29.4 -> 35.2 GB/s;
+        // with the wavefront-wide chain kernel in the rounds 27.7 -> 27.7)
+        const bool big_beside = sthread && n > 16384 && nblocks >= kLzfBigBesideMin;
+        bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big || big_beside);
+        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? (big ? kLzfBigBesideRound : kLzfBesideRound) : ws_bytes / (2 * (size_t)n2);
         const size_t chunk_max = chunk_cap < ws_bytes / (2 * (size_t)n2) ? chunk_cap : ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
         LinkSpace ls;
@@ -1166,7 +1445,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             lgrid = (nblocks + 63) / 64;
             if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
             const char *rs0_env = tune("CW_LANES_RESERVE");
-            const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
+            const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : big ? kLzfBigBesideRound : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
             if (beside && lgrid * 64 + want_reserve > nblocks) lgrid = nblocks > want_reserve + 64 ? (nblocks - want_reserve) / 64 : 1; // (no lane without a block)
             LinkSpace &w = entry->s;
             if (w.lane_cap < lgrid * 64) {
@@ -1200,7 +1479,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                     if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
                 }
                 const char *rs_env = tune("CW_LANES_RESERVE");
-                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
+                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : big ? kLzfBigBesideRound : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
                 if (lane_reserve < 1) lane_reserve = 1; // (0 means "on their own" to the kernel; the protocol itself needs no reserve)
                 if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;
@@ -1241,11 +1520,18 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             const BlockList list = {listed ? ls.handback : nullptr, listed ? ls.counter + kCtrHanded : nullptr, (uint32_t)first};
             const size_t off = listed ? 0 : first; // listed blocks are addressed through the list, from the batch's base
             note(listed ? "cw::lzf_links_kernel (handed-back blocks)" : "cw::lzf_links_kernel");
-            note(big ? "cw::lzf_chain_kernel<true>" : "cw::lzf_chain_kernel<false>");
+            note(sthread ? "cw::lzf_sthread_kernel" : big ? "cw::lzf_chain_kernel<true>" : "cw::lzf_chain_kernel<false>");
             hipLaunchKernelGGL(lzf_links_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), links_lds, stream, src + off * src_stride, n,
                                src_stride, nb, ls.p, n2, sizes + off, force_redo, share, list);
-            const size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
-            if (big)
+            size_t cgrid = nb < 256 * per_cu ? nb : 256 * per_cu;
+            if (sthread) { // (n2 / 8 bytes of LDS per workgroup: 20 per CU at 64 KiB; smaller blocks: as many wavefronts as measured to pay)
+                const size_t st_cu = (160u * 1024u) / (n2 / 8) < st_wpc ? (160u * 1024u) / (n2 / 8) : st_wpc;
+                cgrid = nb < 256 * st_cu ? nb : 256 * st_cu;
+            }
+            if (sthread)
+                hipLaunchKernelGGL(lzf_sthread_kernel, dim3((unsigned)cgrid), dim3(64), n2 / 8, stream, src + off * src_stride, n, src_stride, nb,
+                                   dst + off * dst_stride, dst_stride, sizes + off, ls.p, n2, ls.counter, share, list);
+            else if (big)
                 hipLaunchKernelGGL(lzf_chain_kernel<true>, dim3((unsigned)cgrid), dim3(64), chain_lds, stream, src + off * src_stride, n, src_stride,
                                    nb, dst + off * dst_stride, dst_stride, sizes + off, ls.p, n2, ls.counter, share, list);
             else

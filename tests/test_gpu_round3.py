@@ -147,7 +147,10 @@ LZ4_KNOBS = [
     dict(CW_LZ4_VTAB=0, CW_LZ4_LANES=0, CW_LZ_FORCE_REDO=1),                               # every block through the first-generation redo pass
 ]
 LZF_KNOBS = [
-    dict(CW_LZF_LANES=0),
+    dict(CW_LZF_LANES=0),                                                                  # link/chain rounds: blocks > 4 KiB through the scalar-thread parser
+    dict(CW_LZF_LANES=0, CW_LZF_STHREAD=0),                                                # ... through the wavefront-wide chain kernel
+    dict(CW_LZF_LANES=0, CW_LZF_ST_WPC=1),
+    dict(CW_LZF_LANES=1, CW_LANES_CONCURRENT=1, CW_LZF_ROUND=5, CW_LANES_RESERVE=10),      # lanes beside the rounds at every block size
     dict(CW_LZF_LANES=1),
     dict(CW_LZF_LANES=1, CW_LANES_WPC=1),
     dict(CW_LZF_LANES=1, CW_LZF_ROUND=16),
@@ -183,7 +186,7 @@ def test_every_parser_variant_equals_the_oracle_in_one_process(cw, oracle, comp,
                   "lz4_lanes_ring_kernel<8>", "lz4_lanes_kernel<0>", "lz4_lanes_kernel<1>", "lz4_lanes_kernel<2>", "lz4_parse_fp_kernel<32>", "lz4_parse_kernel<true>", "lz4_parse_kernel<false>", "lz4_vtab3_kernel<true>", "lz4_vtab3_kernel<false>"):
             assert k in joined, (k, joined)
     else:
-        for k in ("lzf_lanes_kernel<true> [side stream]", "lzf_lanes_kernel<false>", "lzf_parse_kernel", "lzf_chain_kernel<true>", "lzf_chain_kernel<false>"):
+        for k in ("lzf_lanes_kernel<true> [side stream]", "lzf_lanes_kernel<false>", "lzf_parse_kernel", "lzf_chain_kernel<true>", "lzf_chain_kernel<false>", "lzf_sthread_kernel"):
             assert k in joined, (k, joined)
 
 
@@ -289,3 +292,34 @@ def test_sequences_at_the_length_field_boundaries(cw, oracle):
         assert "lz4_vtab3_kernel" in names, names
         for i, e in enumerate(want):
             assert int(sizes[i]) == len(e) and payload[i, : len(e)].tobytes() == e, (knobs, i, names)
+
+
+def test_lzf_big_blocks_lanes_beside_scalar_thread_rounds_at_the_default_policy(cw, oracle):
+    """From 96 Ki blocks of more than 16 KiB on the LZF lanes run BESIDE the link / scalar-thread rounds (LaneShare, as for 4 KiB blocks): a
+    6 GiB batch -- a tile of 1,024 corpus-and-noise blocks of 64 KiB repeated 96 times -- at the default policy; every block's size against the
+    oracle's, the payload of the first, a middle and the last tile byte for byte."""
+    import torch
+    bs, tile, reps = 65536, 1024, 96
+    nb = tile * reps
+    a = _corpus_bytes(tile * bs)
+    _, _, osz, opay = oracle.hash_and_compress(a, bs, oracle.HASH_NONE, oracle.COMP_LZF, threads=16, want_payload=True)
+    s = torch.cuda.current_stream().cuda_stream
+    src = torch.from_numpy(a).cuda().repeat(reps)
+    stride = (cw.compress_bound("lzf", bs) + 15) // 16 * 16
+    dst = torch.zeros(nb * stride, dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    cw.dev_compress("lzf", src.data_ptr(), bs, nb, dst.data_ptr(), stride, sizes.data_ptr(), s)
+    torch.cuda.synchronize()
+    names = cw.profile_kernels()["codec"]
+    assert "lzf_lanes_kernel<false> [side stream]" in names and "lzf_sthread_kernel" in names, names
+    want = torch.from_numpy(osz.astype(np.int32)).cuda().repeat(reps)
+    bad = torch.nonzero(sizes != want)
+    assert bad.numel() == 0, (names, bad[:8].flatten().tolist())
+    slots = dst.view(nb, stride)
+    for t in (0, reps // 2, reps - 1):
+        got = slots[t * tile:(t + 1) * tile].cpu().numpy()
+        for i in range(tile):
+            z = int(osz[i])
+            assert got[i, :z].tobytes() == opay[i, :z].tobytes(), (t, i, names)
+    del src, dst, sizes, slots
+    torch.cuda.empty_cache()
