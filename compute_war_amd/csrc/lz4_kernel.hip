@@ -1693,16 +1693,14 @@ __device__ __forceinline__ void lane_store_upto16(uint8_t *p, uint64_t a, uint64
     if (cnt & 1) *p = (uint8_t)a;
 }
 
+// (the body of the two kernels below; ring: the workgroup's (kRingBytes / 4) * 64 dwords of LDS, dword d of lane l's ring at [d * 64 + l]: a lane only
+// touches its column; qcount: the queue's length)
 template <int K>
-__global__ void __launch_bounds__(64)
-lz4_lanes_ring_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
-                      uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
-                      uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve, uint32_t max_blocks)
+__device__ __forceinline__ void
+lz4_lanes_ring_body(uint32_t *__restrict__ ring, const uint32_t qcount, const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst,
+                    size_t dst_stride, uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
+                    uint16_t *__restrict__ tables, uint32_t reserve)
 {
-    __shared__ uint32_t ring[(kRingBytes / 4) * 64]; // dword d of lane l's ring at [d * 64 + l]: a lane only touches its column
-    const uint32_t qcount = counters[1];
-    if (qcount < min_blocks || qcount >= max_blocks) return; // (the queue's length decides on the device which launch parses it)
-    if ((size_t)blockIdx.x * 64 >= qcount) return; // (as in lz4_lanes_kernel)
     const uint32_t lane = threadIdx.x;
     uint32_t *tab = reinterpret_cast<uint32_t *>(tables) + ((size_t)blockIdx.x * 64 + lane) * (1u << 13); // fingerprint:16 | position:16
     const uint32_t mflimit = n - kMFLimit, matchlimit = n - kLastLiterals; // n >= 64
@@ -1971,6 +1969,38 @@ lz4_lanes_ring_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_st
     }
 }
 
+// K positions of a lane's search per iteration, whatever the queue's length within [min_blocks, max_blocks)
+template <int K>
+__global__ void __launch_bounds__(64)
+lz4_lanes_ring_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                      uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
+                      uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve, uint32_t max_blocks)
+{
+    __shared__ uint32_t ring[(kRingBytes / 4) * 64];
+    const uint32_t qcount = counters[1];
+    if (qcount < min_blocks || qcount >= max_blocks) return;
+    if ((size_t)blockIdx.x * 64 >= qcount) return; // (as in lz4_lanes_kernel)
+    lz4_lanes_ring_body<K>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve);
+}
+
+// The launch policy's form: ONE launch, the number of positions per iteration chosen on the device by the queue's length (two below wide_from,
+// one from there on; see lz4_launch).  Until round 3 these were two launches on one stream, each returning at once outside its range -- and from
+// kLaneWideBlocks queued blocks on the second one lost the race for the CUs: while the first launch's workgroups came and went, the register-table
+// and LDS-table parsers of the other streams had filled every CU (the register-table parser alone takes a CU's whole vector register file), and the
+// lanes only started when those ran out of queue: corpus, 64 KiB, 128 Ki / 256 Ki blocks 30.3 / 31.5 GB/s instead of 47.2 / 49.0.
+__global__ void __launch_bounds__(64)
+lz4_lanes_ring_auto_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
+                           uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
+                           uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve_mid, uint32_t wide_from, uint32_t reserve_wide)
+{
+    __shared__ uint32_t ring[(kRingBytes / 4) * 64];
+    const uint32_t qcount = counters[1];
+    if (qcount < min_blocks) return; // (the queue's length decides on the device whether the lanes parse at all)
+    if ((size_t)blockIdx.x * 64 >= qcount) return;
+    if (qcount >= wide_from) lz4_lanes_ring_body<1>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve_wide);
+    else lz4_lanes_ring_body<2>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve_mid);
+}
+
 // per-stream workspace: counters[8] (parse queue head, tail; scan feed; -; second queue head, tail) + two queues
 namespace {
 struct Workspace {
@@ -2215,8 +2245,10 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             note("cw::lz4_lanes_kernel<1> (queue >= %u)%s", lmin, side_tag);
         }
         else if (lanes_ring < 0) {
-            if (lmin < kLaneWideBlocks) CW_RING(2, lmin, kLaneWideBlocks);
-            if (nblocks >= kLaneWideBlocks) CW_RING(1, lmin < kLaneWideBlocks ? kLaneWideBlocks : lmin, no_max);
+            const uint32_t wide_from = lmin < kLaneWideBlocks ? kLaneWideBlocks : lmin;
+            hipLaunchKernelGGL(lz4_lanes_ring_auto_kernel, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
+                               wsp.lane_tabs, lmin, reserve, wide_from, reserve_wide);
+            note("cw::lz4_lanes_ring_auto_kernel (queue >= %u: two positions per iteration, >= %u: one)%s", lmin, wide_from, side_tag);
         }
         else if (lanes_ring == 1) CW_RING(1, lmin, no_max);
         else if (lanes_ring == 2) CW_RING(2, lmin, no_max);

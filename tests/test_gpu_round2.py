@@ -553,5 +553,5 @@ def test_side_by_side_parsers_at_default_thresholds_equal_the_plain_ones():
         # 64 Ki blocks of 4 KiB: as many blocks as a full grid of LZF lanes (every lane asks at once -- the case a check-then-add
         # protocol got wrong); 56 Ki of them queued for LZ4: just below its lanes' threshold, so the launched lane kernel returns at once
         assert ("lanes" in a[5]) == (i != 10) and "lanes" not in b[5], (a, b)   # (32 Ki blocks of 4 KiB: LZF lanes beside the rounds, no LZ4 lanes yet)
-    assert "ring_kernel<2>" in outs[0][4][5] and "[side stream]" in outs[0][4][5], outs[0][4]   # 40 Ki blocks of 64 KiB: lanes beside the other two parsers
+    assert "lz4_lanes_ring_auto_kernel" in outs[0][4][5] and "[side stream]" in outs[0][4][5], outs[0][4]   # 40 Ki blocks of 64 KiB: lanes beside the other two parsers
     assert "[side stream]" in outs[0][0][5] and "[side stream]" in outs[0][1][5] and "[side stream]" in outs[0][3][5]

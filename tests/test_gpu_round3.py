@@ -182,7 +182,7 @@ def test_every_parser_variant_equals_the_oracle_in_one_process(cw, oracle, comp,
                     assert payload[i, : len(e)].tobytes() == e, (knobs, bs, i, names)
     joined = " | ".join(sorted(seen))
     if comp == "lz4":
-        for k in ("lz4_vtab2_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
+        for k in ("lz4_vtab2_kernel", "lz4_lanes_ring_auto_kernel", "lz4_lanes_ring_kernel<1>", "lz4_lanes_ring_kernel<2>", "lz4_lanes_ring_kernel<4>",
                   "lz4_lanes_ring_kernel<8>", "lz4_lanes_kernel<0>", "lz4_lanes_kernel<1>", "lz4_lanes_kernel<2>", "lz4_parse_fp_kernel<32>", "lz4_parse_kernel<true>", "lz4_parse_kernel<false>", "lz4_vtab3_kernel<true>", "lz4_vtab3_kernel<false>"):
             assert k in joined, (k, joined)
     else:
