@@ -24,6 +24,8 @@ cpu_baseline -- that time what uniform noise cannot: the codecs' match/emit path
   corpus_skein256_lz4_4k  the reference's own default pair and block size (hc_sklz4: Skein-256-128 + LZ4 at 4 KiB, run_tests:19)
   corpus_sha256_lzf_4k / _64k   BASELINE configs[3], the reference's hc_shlzf pair (run_tests:20), 4 KiB and 64 KiB
   corpus_skein512_lz4_3233 / _51728   configs[2] at Silesia's literal size (3,233 x 64 KiB = 51,728 x 4 KiB blocks)
+  corpus_skein512_lz4_16g / corpus_sha256_lzf_64k_16g   the two 64 KiB corpus legs at four times the batch (16 GiB = 256 Ki blocks in one call): the
+                        codecs are sets of serial chains, and what a call reaches depends on how many blocks it brings
   corpus_skein256_lzf_4k / corpus_sha256_lz4_4k   the reference's other two pairs (run_tests:14,23)
 plus "host_path" / "host_path_corpus": the drop-in host-buffer entry point over noise and over the corpus (PCIe-inclusive, never `value`).
 After its timed region every leg is checked against the CPU oracle at the leg's own scale ("parity": the corpus legs are periodic, so
@@ -681,13 +683,15 @@ def main():
         #  4 KiB blocks, results/hc_*; context, not a baseline)
         plan = (("mixed", "skein512", "lz4", 65536, "mixed", lb // 65536, 3, None),
                 ("corpus_skein512_lz4", "skein512", "lz4", 65536, "corpus", lb // 65536, 3, None),
+                ("corpus_skein512_lz4_16g", "skein512", "lz4", 65536, "corpus", 4 * lb // 65536, 3, None),
                 ("corpus_skein512_lz4_3233", "skein512", "lz4", 65536, "corpus", 3233, 10, None),
                 ("corpus_skein512_lz4_51728", "skein512", "lz4", 4096, "corpus", 51728, 10, None),
                 ("corpus_skein256_lz4_4k", "skein", "lz4", 4096, "corpus", lb // 4096, 3, 808.3),
                 ("corpus_skein256_lzf_4k", "skein", "lzf", 4096, "corpus", lb // 4096, 3, 704.2),
                 ("corpus_sha256_lz4_4k", "sha256mb", "lz4", 4096, "corpus", lb // 4096, 3, 4899.9),
                 ("corpus_sha256_lzf_4k", "sha256mb", "lzf", 4096, "corpus", lb // 4096, 3, 3127.2),
-                ("corpus_sha256_lzf_64k", "sha256mb", "lzf", 65536, "corpus", lb // 65536, 3, None))
+                ("corpus_sha256_lzf_64k", "sha256mb", "lzf", 65536, "corpus", lb // 65536, 3, None),
+                ("corpus_sha256_lzf_64k_16g", "sha256mb", "lzf", 65536, "corpus", 4 * lb // 65536, 3, None))
         legs = []
         for name, h, c, b, kind, blocks, lsteps, ref_mbps in plan:
             leg, lsample = run_leg(cw, torch, args, name, h, c, b, blocks, kind, lsteps, 1, 1, 0, local_rank, 0, bsec)

@@ -18,11 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LEGS = {"headline": ("skein512", "lz4", 65536, 1 << 20, "random"),
         "mixed": ("skein512", "lz4", 65536, 65536, "mixed"),
         "corpus_skein512_lz4": ("skein512", "lz4", 65536, 65536, "corpus"),
+        "corpus_skein512_lz4_16g": ("skein512", "lz4", 65536, 262144, "corpus"),
         "corpus_skein512_lz4_3233": ("skein512", "lz4", 65536, 3233, "corpus"),
         "corpus_skein512_lz4_51728": ("skein512", "lz4", 4096, 51728, "corpus"),
         "corpus_skein256_lz4_4k": ("skein", "lz4", 4096, 1 << 20, "corpus"),
         "corpus_sha256_lzf_4k": ("sha256mb", "lzf", 4096, 1 << 20, "corpus"),
-        "corpus_sha256_lzf_64k": ("sha256mb", "lzf", 65536, 65536, "corpus")}
+        "corpus_sha256_lzf_64k": ("sha256mb", "lzf", 65536, 65536, "corpus"),
+        "corpus_sha256_lzf_64k_16g": ("sha256mb", "lzf", 65536, 262144, "corpus")}
 
 
 def short(name):
