@@ -941,7 +941,7 @@ lzf_sthread_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_strid
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *skipmap = reinterpret_cast<uint32_t *>(smem); // one bit per position
-    const uint32_t map_lds = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    const uint32_t map_lds = opaque_s((uint32_t)reinterpret_cast<uintptr_t>(smem));
     const uint32_t lane = threadIdx.x;
     const uint32_t cap = n - 1;
 

@@ -51,6 +51,13 @@ __device__ __forceinline__ void sc_load32_8_now(const u32x4 &rs, uint32_t off_a,
     asm volatile("s_buffer_load_dwordx8 %0, %2, %3\n\ts_buffer_load_dwordx2 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(a), "=&s"(b) : "s"(rs), "s"(off_a), "s"(off_b));
 }
+// a value the compiler shall treat as computed once and opaque from here on (the LDS base address of a dynamic array: as an expression it is
+// re-derived -- a null check of the address-space cast, three scalar instructions -- at every use inside the parse loops)
+__device__ __forceinline__ uint32_t opaque_s(uint32_t v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
 // a wave-uniform value moved to a vector register: what is computed from it runs on the VALU
 __device__ __forceinline__ uint32_t to_v(uint32_t s)
 {
