@@ -712,6 +712,10 @@ def main():
         out["legs_key"] = ("value GB/s; ms per step; frac = dominant codec/hash kernel's algorithmic bytes / its time / 8 TB/s; traffic = HBM bytes per launch "
                            "(PMC, profiles/traffic.json); amp = traffic / algorithmic; cpu = oracle port GB/s on `cores` threads, cpu14 = 14 pinned; "
                            "parity = blocks whose size+digest equal the oracle's; rt = blocks decoded on the device and compared")
+        # `value` is measured on incompressible noise (the north star's input): the same pair on the compressible corpus, beside it
+        comp_leg = next((l for l in out["legs"] if l["leg"] == "corpus_skein512_lz4"), None)
+        if comp_leg:
+            out["value_on_compressible_input"] = {"leg": comp_leg["leg"], "value": comp_leg["value"], "unit": "GB/s", "ratio": comp_leg["ratio"]}
         for key, kind in (("host_path", "random"), ("host_path_corpus", "corpus")):
             hp = host_path_leg(cw, torch, "skein512", "lz4", 65536, 8 << 30, kind=kind)
             detail[key] = hp

@@ -1407,6 +1407,7 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // they run BESIDE those two, leaving them kLaneShare blocks of the queue (49,152 blocks: 34.0 -> 40.7 GB/s, 131,072: 44.9 -> 48.3).
 constexpr uint32_t kLaneMidBlocks = 26624, kLaneWideBlocks = 98304; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
 constexpr bool kLtabDefault = true; // corpus, 64 KiB, alone on the queue: 8 Ki / 16 Ki / 48 Ki blocks 16.1 / 17.5 / 18.6 GB/s against the wavefront parser's 14.6 / 15.8 / 16.6; beside the register form 23.3 / 26.7 against 22.2 / 25.4
+constexpr size_t kLaneLeave = 18432;   // blocks > 4 KiB, calls below kLaneWideBlocks: this many blocks get no lane (lz4_launch has the measurements)
 constexpr uint32_t kLaneShare = 24576, kLaneShareWide = 32768;     // blocks of the queue the lanes leave to the other parsers (K = 2 / K = 1 regime)
 constexpr uint32_t kLaneMinSmall = 61440;  // LDS-staged blocks: lanes beside the LDS-resident parser from 60 Ki blocks on (64 Ki blocks of text: 28.5 against 25.7 GB/s)
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
@@ -1991,14 +1992,20 @@ lz4_lanes_ring_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_st
 __global__ void __launch_bounds__(64)
 lz4_lanes_ring_auto_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stride, uint8_t *__restrict__ dst, size_t dst_stride,
                            uint32_t *__restrict__ sizes, const uint32_t *__restrict__ queue, uint32_t *__restrict__ counters,
-                           uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve_mid, uint32_t wide_from, uint32_t reserve_wide)
+                           uint16_t *__restrict__ tables, uint32_t min_blocks, uint32_t reserve_mid, uint32_t wide_from, uint32_t reserve_wide,
+                           uint32_t leave_mid)
 {
     __shared__ uint32_t ring[(kRingBytes / 4) * 64];
     const uint32_t qcount = counters[1];
     if (qcount < min_blocks) return; // (the queue's length decides on the device whether the lanes parse at all)
     if ((size_t)blockIdx.x * 64 >= qcount) return;
-    if (qcount >= wide_from) lz4_lanes_ring_body<1>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve_wide);
-    else lz4_lanes_ring_body<2>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve_mid);
+    if (qcount >= wide_from) {
+        lz4_lanes_ring_body<1>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve_wide);
+    } else {
+        // below wide_from every lane gets one block: no lanes for the leave_mid blocks the on-chip parsers get through meanwhile (lz4_launch)
+        if ((size_t)blockIdx.x * 64 + leave_mid >= qcount && blockIdx.x > 0) return;
+        lz4_lanes_ring_body<2>(ring, qcount, src, n, src_stride, dst, dst_stride, sizes, queue, counters, tables, reserve_mid);
+    }
 }
 
 // per-stream workspace: counters[8] (parse queue head, tail; scan feed; -; second queue head, tail) + two queues
@@ -2188,12 +2195,28 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const char *lw_env = tune("CW_LANES_WPC");
         const size_t lwpc = lw_env && atoi(lw_env) > 0 ? (size_t)atoi(lw_env) : 8;
         size_t lgrid = (nblocks + 63) / 64, lcap = 256 * lwpc;
+        uint32_t lane_leave = 0;
         // LDS-staged blocks, lanes beside the wavefront parser: lanes for about half of the blocks (2 .. 8 wavefronts per CU).  With
         // fewer lanes each is faster (less traffic per probe in flight), and a batch of 64 Ki .. 256 Ki blocks is over before a lane
         // has parsed more than two or three (text, 4 KiB, 80 Ki / 128 Ki / 256 Ki blocks: 2 wavefronts per CU 34.4 / 33.6 / 35.6 GB/s,
         // 4: 27.7 / 39.6 / 36.5, 8: 24.9 / 26.0 / 39.0-41.0; the wavefront parser alone 25.8)
         if (staged && !(lw_env && atoi(lw_env) > 0)) lcap = nblocks / 128 < 512 ? 512 : nblocks / 128 > 2048 ? 2048 : nblocks / 128;
         if (lgrid > lcap) lgrid = lcap;
+        // blocks > 4 KiB, lanes beside the on-chip parsers, calls below kLaneWideBlocks (every lane gets ONE block and the call lasts as long as a lane
+        // needs for it, 60-110 ms depending on how many lanes run): no lanes for the ~18 Ki blocks the two on-chip parsers get through in that time.
+        // A grid with a lane for every block takes the whole queue in its first microseconds (every lane passes the "leave `reserve` blocks" check
+        // before any has drawn) and the on-chip parsers get nothing: 64 Ki blocks, the lanes' kernel 110 ms, the two scalar-thread kernels beside
+        // it 15 ms each.  Corpus, 64 KiB, share of the blocks with a lane 100 / 85 / 72 / 60 / 50 %, GB/s: 32 Ki blocks 32.5 / 33.5 / 33.0 / 35.2 / 37.6,
+        // 48 Ki 42.5 / 43.2 / 44.1 / 46.8 / 39.2, 64 Ki 41.1 / 42.9 / 47.3 / 45.2 / 42.1 (best: all but 16-19 Ki blocks); 128 Ki and 256 Ki blocks
+        // (lanes take several blocks each, the reserve works): 47.8 / 42.6 / 46.5 / 44.6 / 44.7 and 47.6-49.1, no trend.
+        // (the kernel applies the same rule to the queue's length, which may be shorter than the call: blocks the scan has dealt with are not queued)
+        const char *ll_env = tune("CW_LANES_LEAVE"); // blocks of such a call that get no lane (profiling knob; 0 = a lane for every block)
+        const size_t leave = ll_env ? (size_t)atoi(ll_env) : kLaneLeave;
+        if (!staged && leave && !(tune("CW_LANES_CONCURRENT") && tune("CW_LANES_CONCURRENT")[0] == '0') && lane_min > 1) {
+            lane_leave = (uint32_t)leave;
+            const size_t want = nblocks > leave + 4096 ? (nblocks - leave + 63) / 64 : 64;
+            if (nblocks < kLaneWideBlocks && lgrid > want) lgrid = want;
+        }
         if (wsp.lane_cap < lgrid * 64) {
             if (wsp.lane_tabs) { e = hipFree(wsp.lane_tabs); if (e != hipSuccess) return e; }
             wsp.lane_tabs = nullptr; wsp.lane_cap = 0;
@@ -2247,7 +2270,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         else if (lanes_ring < 0) {
             const uint32_t wide_from = lmin < kLaneWideBlocks ? kLaneWideBlocks : lmin;
             hipLaunchKernelGGL(lz4_lanes_ring_auto_kernel, dim3((unsigned)lgrid), dim3(64), 0, ls, src, n, src_stride, dst, dst_stride, sizes, queue, counters,
-                               wsp.lane_tabs, lmin, reserve, wide_from, reserve_wide);
+                               wsp.lane_tabs, lmin, reserve, wide_from, reserve_wide, lane_leave);
             note("cw::lz4_lanes_ring_auto_kernel (queue >= %u: two positions per iteration, >= %u: one)%s", lmin, wide_from, side_tag);
         }
         else if (lanes_ring == 1) CW_RING(1, lmin, no_max);
