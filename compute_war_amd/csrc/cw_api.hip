@@ -170,8 +170,13 @@ struct Slot {
     }
 };
 
+// what the last fused LZ4 call of this thread left behind for the next one: the share of its blocks that the scan queued for the parsers
+// (copied back asynchronously; read when it has arrived, never waited for)
+struct FusedHint { uint32_t *h_queued = nullptr; hipEvent_t ev = nullptr; bool pending = false; size_t blocks_of_copy = 0; float queued_share = 0.f; };
+
 struct ThreadCtx {
     int device = -1;
+    FusedHint hint;
     hipStream_t stream = nullptr;            // kernels of the host-buffer entry points
     hipStream_t s_h2d = nullptr, s_d2h = nullptr; // the two copy directions of the pipelined batch path
     // fork/join for the fused call: the hash runs on `side` beside the codec on the caller's stream
@@ -201,6 +206,8 @@ struct ThreadCtx {
         src.release(); dst.release(); dig.release(); sizes.release();
         for (Slot &s : slot) s.release();
         (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
+        if (hint.ev) (void)hipEventDestroy(hint.ev);
+        if (hint.h_queued) (void)hipHostFree(hint.h_queued);
         cw::release_stream_workspaces(side); cw::release_stream_workspaces(stream);
         (void)hipStreamDestroy(side); (void)hipStreamDestroy(s_h2d); (void)hipStreamDestroy(s_d2h); (void)hipStreamDestroy(stream);
     }
@@ -256,7 +263,7 @@ int dev_hash(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, 
 }
 
 int dev_compress(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t n, uint8_t *d_dst, size_t dst_stride,
-                 uint32_t *d_sizes, hipStream_t s)
+                 uint32_t *d_sizes, hipStream_t s, const cw::AfterScan *after_scan = nullptr)
 {
     hipError_t e;
     if (alg == CW_COMP_NONE) return CW_OK;
@@ -265,7 +272,7 @@ int dev_compress(int alg, const uint8_t *d_src, size_t bb, size_t stride, size_t
     if (dst_stride < cw_compress_bound(alg, bb))
         return fail(CW_ERR_BAD_ARG, "dst_stride %zu < bound %zu", dst_stride, cw_compress_bound(alg, bb));
     ProfScope prof(PROF_CODEC, s);
-    e = alg == CW_COMP_LZ4 ? cw::lz4_launch(d_src, bb, stride, n, d_dst, dst_stride, d_sizes, s)
+    e = alg == CW_COMP_LZ4 ? cw::lz4_launch(d_src, bb, stride, n, d_dst, dst_stride, d_sizes, s, after_scan)
                            : cw::lzf_launch(d_src, bb, stride, n, d_dst, dst_stride, d_sizes, s);
     if (e != hipSuccess) return fail(CW_ERR_HIP, "compress launch: %s", hipGetErrorString(e));
     return CW_OK;
@@ -456,10 +463,51 @@ static int dev_fused(hipStream_t side, hipEvent_t fork, hipEvent_t join, int has
     }
     HIP_TRY(hipEventRecord(fork, main_s));
     HIP_TRY(hipStreamWaitEvent(side, fork, 0));
-    rc = dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, main_s);
-    if (rc == CW_OK) rc = dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, side, false, true);
+    // Side by side pays when the codec is light -- incompressible input, where it is the scan alone (the headline: 61.7 ms against 72.9 one after
+    // the other).  On compressible input the parsers fill every CU with wavefronts that stay until the queue is empty; a hash kernel that arrives
+    // beside them trickles in behind, ends with the call and costs the parsers more than it takes alone (Skein-256 over 1 Mi blocks of 4 KiB:
+    // 3.5 ms alone, but the fused call 97.7 ms against 84.8 one after the other; 51,728 blocks 8.7 against 6.8 ms).  Which input a call has is known
+    // on the device only -- but calls come in streams of alike ones, so the LAST LZ4 call's queued share decides (copied back asynchronously, used
+    // when it has arrived): a quarter or more of the blocks queued, at least 16 Ki blocks (fewer leave CUs idle for the hash anyway), and blocks of
+    // at most 4 KiB => the hash is enqueued right behind the scan, runs beside it, and the PARSERS WAIT FOR IT.  Measured, fused call gated / not:
+    // Skein-256 + LZ4, 1 Mi blocks of 4 KiB 93.3 / 104.2 ms, SHA-256 + LZ4 92.2 / 101.6, 51,728 blocks 7.15 / 7.55; blocks of 64 KiB, where the
+    // scalar-thread parsers leave the vector ALUs to the hash: 64 Ki blocks 94.8 / 91.1 ms, the mix 43.4 / 42.2, 256 Ki blocks 370.6 / 372.0 -- so
+    // those stay side by side.  (Always gating costs the headline 2.7 ms: its empty-queue parser and redo launches then run behind the hash.)
+    struct Gate { int hash_alg; const uint8_t *src; size_t bb, stride, n; uint8_t *dig; hipStream_t side, main_s; hipEvent_t join; int rc; bool called; };
+    Gate gate = {hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, side, main_s, join, CW_OK, false};
+    const cw::AfterScan hook = {[](void *p) -> hipError_t {
+                                    Gate *g = static_cast<Gate *>(p);
+                                    g->called = true;
+                                    g->rc = dev_hash(g->hash_alg, g->src, g->bb, g->stride, g->n, g->dig, g->side, false, true);
+                                    if (g->rc != CW_OK) return hipErrorUnknown;
+                                    hipError_t e = hipEventRecord(g->join, g->side);
+                                    return e == hipSuccess ? hipStreamWaitEvent(g->main_s, g->join, 0) : e;
+                                }, &gate};
+    ThreadCtx *tc = nullptr;
+    FusedHint *hint = comp_alg == CW_COMP_LZ4 && thread_ctx(&tc) == CW_OK ? &tc->hint : nullptr;
+    if (hint && hint->pending && hipEventQuery(hint->ev) == hipSuccess) {
+        hint->pending = false;
+        if (hint->blocks_of_copy) hint->queued_share = (float)*hint->h_queued / (float)hint->blocks_of_copy;
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady of the query is not an error)
+    const char *gate_env = cw::tune("CW_FUSED_GATE"); // 0 = never, 1 = always (profiling knob)
+    const bool gated = hint && (gate_env ? gate_env[0] == '1' : block_bytes <= 4096 && nblocks >= 16384 && hint->queued_share >= 0.25f);
+    rc = dev_compress(comp_alg, d_src, block_bytes, src_stride, nblocks, d_dst, dst_stride, d_sizes, main_s, gated ? &hook : nullptr);
+    if (gate.called && gate.rc != CW_OK) return gate.rc;
+    if (rc == CW_OK && !gate.called) rc = dev_hash(hash_alg, d_src, block_bytes, src_stride, nblocks, d_digests, side, false, true);
     HIP_TRY(hipEventRecord(join, side));
     HIP_TRY(hipStreamWaitEvent(main_s, join, 0));
+    if (rc == CW_OK && hint && !hint->pending) { // this call's queued share, for the next call
+        const uint32_t *word = cw::lz4_queued_blocks_word(main_s);
+        if (word) {
+            if (!hint->h_queued) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hint->h_queued), 64, hipHostMallocDefault));
+            if (!hint->ev) HIP_TRY(hipEventCreateWithFlags(&hint->ev, hipEventDisableTiming));
+            HIP_TRY(hipMemcpyAsync(hint->h_queued, word, sizeof(uint32_t), hipMemcpyDeviceToHost, main_s));
+            HIP_TRY(hipEventRecord(hint->ev, main_s));
+            hint->pending = true;
+            hint->blocks_of_copy = nblocks;
+        }
+    }
     return rc;
 }
 

@@ -85,8 +85,12 @@ hipError_t skein256_launch(const uint8_t *src, size_t block_bytes, size_t src_st
                            uint8_t *digests, unsigned digest_bytes, hipStream_t stream, bool lean = false);
 hipError_t sha256_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *digests,
                          hipStream_t stream);
+// after_scan (optional): called ONCE, right behind the launch of the scan and in front of everything else, if the call gets that far (the caller
+// checks): what it enqueues on other streams runs beside the scan; what it makes `stream` wait for, the parsers wait for
+struct AfterScan { hipError_t (*fn)(void *ctx); void *ctx; };
 hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
-                      size_t dst_stride, uint32_t *sizes, hipStream_t stream);
+                      size_t dst_stride, uint32_t *sizes, hipStream_t stream, const AfterScan *after_scan = nullptr);
+const uint32_t *lz4_queued_blocks_word(hipStream_t stream);
 hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride, size_t nblocks, uint8_t *dst,
                       size_t dst_stride, uint32_t *sizes, hipStream_t stream);
 // LZ4 parser with the table in vector registers (lz4_vtab_kernel.hip): parses blocks of the scan's queue (counters[0] = head,
