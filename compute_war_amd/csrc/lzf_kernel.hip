@@ -1113,7 +1113,10 @@ constexpr uint32_t kLzfLaneMinSmall = 28672;  // blocks <= 4 KiB: lanes beside t
 constexpr size_t kLzfBesideRound = 16384;     // ... in rounds of 16 Ki blocks, the last 16 Ki unclaimed blocks left to the rounds.  4 KiB blocks, text /
                                               // 50 % noise / noise, GB/s -- 1 Mi blocks: rounds of 8 Ki 29.8 / 24.7 / 52.9, 16 Ki 33.1 / 29.0 / 57.7,
                                               // 32 Ki 32.6 / 30.9 / 59.2; 96 Ki blocks: 25.6 / 36.3 / 50.5, 26.2 / 39.3 / 53.6, 23.1 / 36.4 / 55.0
-constexpr size_t kLzfBigBesideMin = 98304, kLzfBigBesideRound = 8192; // blocks > 16 KiB: lanes beside the rounds from 96 Ki blocks on, rounds of 8 Ki blocks, as many left to the rounds
+// blocks > 16 KiB: lanes beside the scalar-thread rounds from 52 Ki blocks on; from 96 Ki blocks on rounds of 8 Ki blocks and as many left to the rounds, below
+// (every lane gets one block; the rounds get what they manage in that time) rounds of 4 Ki and 12 Ki blocks left.  Corpus, 64 KiB, lanes alone -> beside:
+// 48 Ki blocks 27.0 -> 26.3-27.6 (not used), 56 Ki 27.0 -> 29.1, 64 Ki 27.3 -> 29.0, 80 Ki 26.4 -> 34.8, 128 Ki 27.3 -> 31.0, 256 Ki 29.4 -> 35.2 GB/s
+constexpr size_t kLzfBigBesideMin = 53248, kLzfBigBesideWide = 98304, kLzfBigBesideRound = 8192, kLzfBigBesideRoundMid = 4096, kLzfBigBesideReserveMid = 12288;
 constexpr uint32_t kLzfBesideReserve = 16384, kLzfBesideReserveFew = 8192; // blocks left to the rounds; below 48 Ki blocks (32 Ki blocks: 16.1 against 13.2 GB/s with 16 Ki)
 
 // 4 bytes at ip (ip + 2 < n): the last position of a block is read one byte early and shifted (no read past the block)
@@ -1403,11 +1406,10 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         const size_t st_wpc = stw_env && atoi(stw_env) > 0 ? (size_t)atoi(stw_env) : 20;
         const bool sthread = big && (st_env ? st_env[0] != '0' : true) && ((reinterpret_cast<uintptr_t>(src) | src_stride) & 3) == 0;
         // lanes BESIDE the rounds: blocks <= 4 KiB always; larger blocks from kLzfBigBesideMin blocks on, and only with the scalar-thread
-        // parser in the rounds (corpus, 64 KiB, lanes alone -> beside: 64 Ki blocks 27.3-28.7 -> 28.4, 128 Ki 27.3 -> 30.3, 256 Ki 29.4 -> 35.2 GB/s;
-        // with the wavefront-wide chain kernel in the rounds 27.7 -> 27.7)
+        // parser in the rounds (with the wavefront-wide chain kernel in the rounds: 256 Ki blocks 27.7 -> 27.7 GB/s)
         const bool big_beside = sthread && n > 16384 && nblocks >= kLzfBigBesideMin;
         bool beside = use_lanes && (cc_env ? cc_env[0] != '0' : !big || big_beside);
-        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? (big ? kLzfBigBesideRound : kLzfBesideRound) : ws_bytes / (2 * (size_t)n2);
+        const size_t chunk_cap = round_env && atoi(round_env) > 0 ? (size_t)atoi(round_env) : beside ? (big ? (nblocks < kLzfBigBesideWide ? kLzfBigBesideRoundMid : kLzfBigBesideRound) : kLzfBesideRound) : ws_bytes / (2 * (size_t)n2);
         const size_t chunk_max = chunk_cap < ws_bytes / (2 * (size_t)n2) ? chunk_cap : ws_bytes / (2 * (size_t)n2);
         const size_t chunk = nblocks < chunk_max ? nblocks : chunk_max;
         LinkSpace ls;
@@ -1445,7 +1447,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             lgrid = (nblocks + 63) / 64;
             if (lgrid > 256 * lwpc) lgrid = 256 * lwpc;
             const char *rs0_env = tune("CW_LANES_RESERVE");
-            const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : big ? kLzfBigBesideRound : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
+            const size_t want_reserve = rs0_env && atoi(rs0_env) > 0 ? (size_t)atoi(rs0_env) : big ? (nblocks < kLzfBigBesideWide ? kLzfBigBesideReserveMid : kLzfBigBesideRound) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
             if (beside && lgrid * 64 + want_reserve > nblocks) lgrid = nblocks > want_reserve + 64 ? (nblocks - want_reserve) / 64 : 1; // (no lane without a block)
             LinkSpace &w = entry->s;
             if (w.lane_cap < lgrid * 64) {
@@ -1479,7 +1481,7 @@ hipError_t lzf_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
                     if ((e = hipEventCreateWithFlags(&w.join, hipEventDisableTiming)) != hipSuccess) return e;
                 }
                 const char *rs_env = tune("CW_LANES_RESERVE");
-                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : big ? kLzfBigBesideRound : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
+                lane_reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : big ? (nblocks < kLzfBigBesideWide ? kLzfBigBesideReserveMid : kLzfBigBesideRound) : nblocks < 49152 ? kLzfBesideReserveFew : kLzfBesideReserve;
                 if (lane_reserve < 1) lane_reserve = 1; // (0 means "on their own" to the kernel; the protocol itself needs no reserve)
                 if ((e = hipEventRecord(w.fork, stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(w.side, w.fork, 0)) != hipSuccess) return e;
