@@ -294,12 +294,13 @@ def test_sequences_at_the_length_field_boundaries(cw, oracle):
             assert int(sizes[i]) == len(e) and payload[i, : len(e)].tobytes() == e, (knobs, i, names)
 
 
-def test_lzf_big_blocks_lanes_beside_scalar_thread_rounds_at_the_default_policy(cw, oracle):
-    """From 96 Ki blocks of more than 16 KiB on the LZF lanes run BESIDE the link / scalar-thread rounds (LaneShare, as for 4 KiB blocks): a
-    6 GiB batch -- a tile of 1,024 corpus-and-noise blocks of 64 KiB repeated 96 times -- at the default policy; every block's size against the
-    oracle's, the payload of the first, a middle and the last tile byte for byte."""
+@pytest.mark.parametrize("reps", [56, 96])
+def test_lzf_big_blocks_lanes_beside_scalar_thread_rounds_at_the_default_policy(cw, oracle, reps):
+    """From 52 Ki blocks of more than 16 KiB on the LZF lanes run BESIDE the link / scalar-thread rounds (LaneShare, as for 4 KiB blocks; rounds of
+    4 Ki blocks below 96 Ki blocks, of 8 Ki from there on): a tile of 1,024 corpus-and-noise blocks of 64 KiB repeated 56 and 96 times (3.5 and
+    6 GiB) at the default policy; every block's size against the oracle's, the payload of the first, a middle and the last tile byte for byte."""
     import torch
-    bs, tile, reps = 65536, 1024, 96
+    bs, tile = 65536, 1024
     nb = tile * reps
     a = _corpus_bytes(tile * bs)
     _, _, osz, opay = oracle.hash_and_compress(a, bs, oracle.HASH_NONE, oracle.COMP_LZF, threads=16, want_payload=True)
