@@ -436,7 +436,9 @@ def run_leg(cw, torch, args, name, hash_name, comp_name, bs, nb, kind, steps, wa
     csize = bytes_out / total_blocks
     alg_bytes = {"hash": bs + db, "comp": bs + csize + 4}   # the hash reads the block, writes its digest; the codec reads it, writes csize + 4
     launches = {"hash": 8 if "slice" in names["hash"] else 1, "comp": 1}
-    dom = max(k_ms, key=k_ms.get)
+    # the kernel the step is bound by.  The two event spans say so only while the hash is the longer job (incompressible input); beside busy parsers
+    # the hash's launches trickle in and its span is the whole call whatever its work, so on compressible input it is the codec
+    dom = max(k_ms, key=k_ms.get) if kind == "random" or not k_ms.get("comp") else "comp"
     kernels = {k: {"name": names["codec" if k == "comp" else "hash"], "ms_per_step": round(k_ms[k], 3), "launches_per_step": launches[k],
                    "ms_per_launch": round(k_ms[k] / launches[k], 3),
                    "alg_GBps": round(alg_bytes[k] * nb / (k_ms[k] / 1e3) / 1e9, 1) if k_ms[k] else None,
