@@ -1417,10 +1417,13 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // Round 3: below kLaneMidBlocks the register-table parser beside the wavefront parser wins (corpus, 64 KiB: 12 Ki / 16 Ki / 24 Ki / 28 Ki blocks
 // 23.9 / 25.1 / 26.1 / 26.5 GB/s against the lanes' 15.4 / 19.5 / 24.1 / 28.8), so the lanes start later than in round 2 (10,240), and from there on
 // they run BESIDE those two, leaving them kLaneShare blocks of the queue (49,152 blocks: 34.0 -> 40.7 GB/s, 131,072: 44.9 -> 48.3).
-constexpr uint32_t kLaneMidBlocks = 26624, kLaneWideBlocks = 98304; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
+constexpr uint32_t kLaneMidBlocks = 22528, kLaneWideBlocks = 98304; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
 constexpr bool kLtabDefault = true; // corpus, 64 KiB, alone on the queue: 8 Ki / 16 Ki / 48 Ki blocks 16.1 / 17.5 / 18.6 GB/s against the wavefront parser's 14.6 / 15.8 / 16.6; beside the register form 23.3 / 26.7 against 22.2 / 25.4
 constexpr size_t kLaneLeave = 18432;   // blocks > 4 KiB, calls below kLaneWideBlocks: this many blocks get no lane (lz4_launch has the measurements)
-constexpr uint32_t kLaneShare = 24576, kLaneShareWide = 32768;     // blocks of the queue the lanes leave to the other parsers (K = 2 / K = 1 regime)
+constexpr uint32_t kLaneShare = 24576, kLaneShareWide = 32768;     // blocks of the queue the lanes leave to the other parsers (K = 2 / K = 1 regime); K = 2: at most two thirds of
+                                                                   // the call -- since the lanes no longer take the whole queue at once (kLaneLeave) they pay from 22 Ki blocks on: corpus,
+                                                                   // 64 KiB, 20 Ki / 24 Ki / 28 Ki blocks without lanes 29.0 / 29.4 / 29.8 GB/s, with 28.2 / 31.7 / 35.3 (16 Ki left);
+                                                                   // 56 Ki / 72 Ki blocks with 16 Ki left 39.9-43.9 / 43.2-48.1, with 24 Ki 47.1 / 48.2-48.7
 constexpr uint32_t kLaneMinSmall = 61440;  // LDS-staged blocks: lanes beside the LDS-resident parser from 60 Ki blocks on (64 Ki blocks of text: 28.5 against 25.7 GB/s)
 enum : uint32_t { LS_NEXT = 0, LS_PROBE = 1, LS_EMIT = 2, LS_TAIL = 3, LS_EXIT = 4 };
 
@@ -2268,6 +2271,7 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
             // blocks > 4 KiB (round 3; corpus, 64 KiB, lanes alone -> lanes beside the other two, GB/s): two positions per iteration, 32 Ki blocks
             // 29.4 -> 31.0 (reserve 24 Ki), 48 Ki 34.0 -> 40.7 (16-24 Ki), 64 Ki 37.2 -> 40.6 (32 Ki); one position: 128 Ki 44.9 -> 48.3 (32 Ki), 256 Ki 42.8 -> 46.7
             reserve = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : (staged ? 32768u : kLaneShare);
+            if (!staged && !(rs_env && atoi(rs_env) > 0) && reserve > nblocks / 3 * 2) reserve = (uint32_t)(nblocks / 3 * 2);
             reserve_wide = rs_env && atoi(rs_env) > 0 ? (uint32_t)atoi(rs_env) : kLaneShareWide;
             if (lane_min > 1 && lmin < reserve + reserve / 4) lmin = reserve + reserve / 4; // (CW_LZ4_LANES=1 in the tests: no reserve)
             if (lane_min == 1) reserve = reserve_wide = 0;
