@@ -1414,9 +1414,10 @@ lz4_parse_fp_kernel(const uint8_t *__restrict__ src, uint32_t n, size_t src_stri
 // ---------------------------------------------------------------------------------------------------
 // blocks > 4 KiB: below kLaneMidBlocks queued blocks the wavefront-per-block parser's 13-14 GB/s win; [mid, wide): lanes with two
 // positions per iteration (every lane holds one block: latency regime), from kLaneWideBlocks on one (random-line regime); lz4_launch
-// Round 3: below kLaneMidBlocks the register-table parser beside the wavefront parser wins (corpus, 64 KiB: 12 Ki / 16 Ki / 24 Ki / 28 Ki blocks
-// 23.9 / 25.1 / 26.1 / 26.5 GB/s against the lanes' 15.4 / 19.5 / 24.1 / 28.8), so the lanes start later than in round 2 (10,240), and from there on
-// they run BESIDE those two, leaving them kLaneShare blocks of the queue (49,152 blocks: 34.0 -> 40.7 GB/s, 131,072: 44.9 -> 48.3).
+// Round 3: below kLaneMidBlocks the two scalar-thread parsers (table in vector registers / in LDS, lz4_vtab_kernel.hip) win (corpus, 64 KiB: 12 Ki /
+// 16 Ki / 20 Ki blocks 23.9 / 27.3 / 29.0 GB/s against the lanes' 15.4 / 19.5 / ~22), so the lanes start later than in round 2 (10,240), and from there on
+// they run BESIDE those two: in the one-block-per-lane regime there are no lanes for kLaneLeave blocks of the queue and the lanes leave kLaneShare
+// blocks (two thirds of a small call) alone; from kLaneWideBlocks on they leave kLaneShareWide.  One launch for both regimes (lz4_lanes_ring_auto_kernel).
 constexpr uint32_t kLaneMidBlocks = 22528, kLaneWideBlocks = 98304; // (blocks <= 32 KiB: higher lower thresholds, lz4_launch)
 constexpr bool kLtabDefault = true; // corpus, 64 KiB, alone on the queue: 8 Ki / 16 Ki / 48 Ki blocks 16.1 / 17.5 / 18.6 GB/s against the wavefront parser's 14.6 / 15.8 / 16.6; beside the register form 23.3 / 26.7 against 22.2 / 25.4
 constexpr size_t kLaneLeave = 18432;   // blocks > 4 KiB, calls below kLaneWideBlocks: this many blocks get no lane (lz4_launch has the measurements)
