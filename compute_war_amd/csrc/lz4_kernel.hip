@@ -2263,7 +2263,20 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         uint32_t reserve = 0, reserve_wide = 0, lmin = lane_min;
         if (lanes_beside) {
             if (!wsp.side) {
-                if ((e = hipStreamCreateWithFlags(&wsp.side, hipStreamNonBlocking)) != hipSuccess) return e;
+                {   // The lanes' and the register-table parser's streams come from the HIGH-PRIORITY pool of hardware queues (CW_SIDE_PRIO=0: the normal one,
+                    // =1: the lanes' only).  HIP multiplexes its streams onto four hardware queues per priority level, and kernels of different streams
+                    // that land on one queue run one after the other.  A device-resident call has four streams and is not affected; the host pipeline has
+                    // three slots with four streams each plus two for copies, and its timeline (rocprofv3 --kernel-trace) showed a chunk's two scalar-thread
+                    // kernels starting the moment ITS OWN lanes kernel had ended, 108 ms late.  With the side streams in another pool a chunk's kernels
+                    // no longer share a queue with each other: host path over the corpus 20.5-21.0 -> 24.0-24.3 GB/s (GPU_MAX_HW_QUEUES=8 on top: 24.7-24.9);
+                    // the device-resident legs and the headline are unchanged (16 GiB corpus leg 44-48 -> 49.6).
+                    const char *sp_env = tune("CW_SIDE_PRIO");
+                    int least = 0, greatest = 0;
+                    if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess) return e;
+                    e = !(sp_env && sp_env[0] == '0') ? hipStreamCreateWithPriority(&wsp.side, hipStreamNonBlocking, greatest)
+                                                   : hipStreamCreateWithFlags(&wsp.side, hipStreamNonBlocking);
+                    if (e != hipSuccess) return e;
+                }
                 if ((e = hipEventCreateWithFlags(&wsp.fork, hipEventDisableTiming)) != hipSuccess) return e;
                 if ((e = hipEventCreateWithFlags(&wsp.join, hipEventDisableTiming)) != hipSuccess) return e;
             }
@@ -2340,7 +2353,14 @@ hipError_t lz4_launch(const uint8_t *src, size_t block_bytes, size_t src_stride,
         hipStream_t vs = stream;
         if (vt_mode == 2) {
             if (!wsp.side2) {
-                if ((e = hipStreamCreateWithFlags(&wsp.side2, hipStreamNonBlocking)) != hipSuccess) return e;
+                {
+                    const char *sp_env = tune("CW_SIDE_PRIO");
+                    int least = 0, greatest = 0;
+                    if ((e = hipDeviceGetStreamPriorityRange(&least, &greatest)) != hipSuccess) return e;
+                    e = !(sp_env && sp_env[0] != '2') ? hipStreamCreateWithPriority(&wsp.side2, hipStreamNonBlocking, greatest)
+                                                   : hipStreamCreateWithFlags(&wsp.side2, hipStreamNonBlocking);
+                    if (e != hipSuccess) return e;
+                }
                 if ((e = hipEventCreateWithFlags(&wsp.fork2, hipEventDisableTiming)) != hipSuccess) return e;
                 if ((e = hipEventCreateWithFlags(&wsp.join2, hipEventDisableTiming)) != hipSuccess) return e;
             }
