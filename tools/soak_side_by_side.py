@@ -23,7 +23,8 @@ rng = np.random.default_rng(2026)
 CASES = [("lzf", 4096, nb) for nb in (49152, 57344, 65536, 70001, 98304, 131072, 200000, 524288)] + \
         [("lzf", 2048, nb) for nb in (65536, 150000)] + [("lzf", 1000, 120000)] + \
         [("lz4", 4096, nb) for nb in (98304, 100001, 131072, 262144, 524288)] + [("lz4", 2048, 200000), ("lz4", 1000, 150000)] + \
-        [("lzf", 65536, nb) for nb in (24576, 30000, 65536)] + [("lz4", 65536, nb) for nb in (24576, 30000, 65536)] + \
+        [("lzf", 65536, nb) for nb in (24576, 30000, 53248, 57344, 65536, 81920, 100001)] + \
+        [("lz4", 65536, nb) for nb in (22528, 24576, 30000, 40960, 57344, 65536, 81920, 98304, 100001, 140000)] + \
         [("lzf", 16384, 100000), ("lz4", 16384, 100000), ("lzf", 20000, 30000), ("lz4", 20000, 30000)]
 for ci, (comp, bs, nb) in enumerate(CASES):
     total = nb * bs
