@@ -141,13 +141,18 @@ struct Slot {
     hipEvent_t ev_h2d = nullptr, ev_meta = nullptr, ev_payload = nullptr;
     size_t first = 0, n = 0;
     uint64_t total = 0;
-    int open()
+    bool borrowed = false; // stream and side belong to the thread's first slot (CW_HOST_SHARED_STREAMS)
+    int open(const Slot *lender = nullptr)
     {
         if (ev_h2d) return CW_OK;
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
+        if (lender && lender->stream) {
+            stream = lender->stream; side = lender->side; borrowed = true;
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
+        }
         HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&join, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_meta, hipEventDisableTiming));
@@ -159,8 +164,9 @@ struct Slot {
     {
         src.release(); dst.release(); pack.release(); sizes.release(); offs.release(); dig.release();
         h_src.release(); h_meta.release(); h_pack.release();
-        if (stream) { cw::release_stream_workspaces(stream); (void)hipStreamDestroy(stream); }
-        if (side) { cw::release_stream_workspaces(side); (void)hipStreamDestroy(side); }
+        if (stream && !borrowed) { cw::release_stream_workspaces(stream); (void)hipStreamDestroy(stream); }
+        if (side && !borrowed) { cw::release_stream_workspaces(side); (void)hipStreamDestroy(side); }
+        borrowed = false;
         if (fork) (void)hipEventDestroy(fork);
         if (join) (void)hipEventDestroy(join);
         if (ev_meta) (void)hipEventDestroy(ev_meta);
@@ -708,11 +714,27 @@ bool is_pinned(const void *p)
 size_t meta_off_total(size_t n) { return (n * 4 + 7) & ~(size_t)7; }
 size_t meta_off_dig(size_t n) { return meta_off_total(n) + 8; }
 
-int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack);
+int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack, const Slot *lender = nullptr);
+
+// The slots of a thread's pipeline share ONE pair of kernel streams (the first slot's) unless the job's codec is LZF (CW_HOST_SHARED_STREAMS=0|1
+// forces either; decided when a slot is first opened).  HIP multiplexes streams onto four hardware queues per priority level, and kernels -- and the
+// small device-to-host copies of a chunk's sizes and digests -- that land on one queue wait for each other: with a stream pair per slot (plus the
+// codec's side streams per slot stream) the pipeline had sixteen streams, and its timeline showed a chunk's copies and kernels waiting behind
+// another chunk's long kernels.  The chunks' kernels do not gain from overlapping each other anyway.  8 GiB through
+// cw_hash_and_compress_packed, own streams -> shared: corpus, Skein-512 + LZ4, 64 KiB 24.1 -> 26.0 GB/s; Skein-256 + LZ4, 4 KiB 22.6 -> 33.4;
+// SHA-256 + LZ4, 4 KiB 23.0 -> 33.5; noise 41.4 -> 43.6; SHA-256 + LZF, 4 KiB 25.5 -> 25.6, 64 KiB 17.6 -> 15.9 (its rounds of link and parse
+// kernels do overlap across chunks).
+const Slot *shared_lender(ThreadCtx &c, const HostJob &j, const Slot &s)
+{
+    const char *sh_env = cw::tune("CW_HOST_SHARED_STREAMS");
+    const bool share = sh_env ? sh_env[0] == '1' : j.comp_alg != CW_COMP_LZF;
+    if (!share || &s == &c.slot[0]) return nullptr;
+    return c.slot[0].open() == CW_OK ? &c.slot[0] : nullptr;
+}
 
 int pipe_issue(ThreadCtx &c, HostJob &j, Slot &s, size_t first, size_t n)
 {
-    int rc = slot_reserve(j, s, n, !j.src_pinned, !(j.packed && j.packed_pinned));
+    int rc = slot_reserve(j, s, n, !j.src_pinned, !(j.packed && j.packed_pinned), shared_lender(c, j, s));
     if (rc != CW_OK) return rc;
     s.first = first; s.n = n; s.total = 0;
     const size_t bytes = n * j.bb;
@@ -824,9 +846,9 @@ size_t pipeline_chunk(size_t bb, size_t nblocks)
 }
 
 // device buffers, pinned staging, streams and events of one slot for chunks of n blocks (idempotent; grows only)
-int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack)
+int slot_reserve(HostJob &j, Slot &s, size_t n, bool stage_src, bool stage_pack, const Slot *lender)
 {
-    int rc = s.open();
+    int rc = s.open(lender);
     if (rc != CW_OK) return rc;
     if ((rc = s.src.reserve(n * j.bb + 16)) != CW_OK) return rc;
     if (j.do_hash && (rc = s.dig.reserve(n * j.db)) != CW_OK) return rc;
@@ -978,7 +1000,7 @@ int cw_prepare(int hash_alg, int comp_alg, size_t block_bytes, size_t nblocks, i
     const size_t big = grown_chunk(j, chunk, pinned_io != 0);
     if (big && nblocks > 2 * chunk && room_to_grow(*c, j, big)) chunk = nblocks - 2 * chunk < big ? nblocks - 2 * chunk : big;
     for (Slot &s : c->slot)
-        if ((rc = slot_reserve(j, s, chunk, !pinned_io, !pinned_io)) != CW_OK) return rc;
+        if ((rc = slot_reserve(j, s, chunk, !pinned_io, !pinned_io, shared_lender(*c, j, s))) != CW_OK) return rc;
     // One chunk's kernels on every slot (over whatever its device buffers hold): the codecs' per-stream workspaces -- queues, link
     // arrays, the lane parsers' tables -- are allocated here instead of inside the first timed batch, and the device leaves its
     // idle clocks.  Then a few copies each way to wake the link (the first pass after idle ran at 25-29 GB/s against 45.7).
