@@ -324,3 +324,58 @@ def test_lzf_big_blocks_lanes_beside_scalar_thread_rounds_at_the_default_policy(
             assert got[i, :z].tobytes() == opay[i, :z].tobytes(), (t, i, names)
     del src, dst, sizes, slots
     torch.cuda.empty_cache()
+
+
+def test_fused_call_gated_and_side_by_side_give_the_same_bytes(cw, oracle):
+    """Blocks of up to 4 KiB, 16 Ki blocks or more, a compressible previous call: the fused call enqueues the hash behind the scan and lets the parsers
+    wait for it (cw_api.hip, dev_fused).  Forced on, forced off and decided by the call history (three calls in a row), every digest, size and payload
+    byte equals the oracle's."""
+    import torch
+    bs, nb = 4096, 24576
+    a = _corpus_bytes(nb * bs)
+    _, odig, osz, opay = oracle.hash_and_compress(a, bs, oracle.HASH_SKEIN256_128, oracle.COMP_LZ4, threads=16, want_payload=True)
+    s = torch.cuda.current_stream().cuda_stream
+    src = torch.from_numpy(a).cuda()
+    stride = (cw.compress_bound("lz4", bs) + 15) // 16 * 16
+    for knobs, calls in ((dict(CW_FUSED_GATE=1), 1), (dict(CW_FUSED_GATE=0), 1), (dict(), 3)):
+        with cw.tuned(**knobs):
+            for _ in range(calls):
+                dst = torch.zeros(nb * stride, dtype=torch.uint8, device="cuda")
+                sizes = torch.zeros(nb, dtype=torch.int32, device="cuda")
+                dig = torch.zeros((nb, 16), dtype=torch.uint8, device="cuda")
+                cw.dev_hash_and_compress("skein", "lz4", src.data_ptr(), bs, nb, dig.data_ptr(), dst.data_ptr(), stride, sizes.data_ptr(), s)
+                torch.cuda.synchronize()
+                assert np.array_equal(sizes.cpu().numpy().astype(np.uint32), osz), knobs
+                assert np.array_equal(dig.cpu().numpy(), odig), knobs
+                slots = dst.view(nb, stride).cpu().numpy()
+                for i in range(0, nb, 5):
+                    z = int(osz[i])
+                    assert slots[i, :z].tobytes() == opay[i, :z].tobytes(), (knobs, i)
+
+
+def test_host_pipeline_with_shared_and_with_own_slot_streams(cw, oracle):
+    """The host pipeline's slots share one pair of kernel streams for LZ4 jobs (cw_api.hip, shared_lender; decided when a thread's slots are first
+    opened, so each setting runs in a thread of its own): both forms, over enough blocks for several chunks, equal the oracle."""
+    import threading
+    bs, nb = 65536, 4096          # 256 MiB: CW_HOST_CHUNK_MB=32 makes it eight chunks
+    a = _corpus_bytes(nb * bs)
+    _, odig, osz, opay = oracle.hash_and_compress(a, bs, oracle.HASH_SKEIN512, oracle.COMP_LZ4, threads=16, want_payload=True)
+    want = b"".join(opay[i, : int(osz[i])].tobytes() for i in range(nb))
+    errors = []
+
+    def run(shared):
+        try:
+            cw.init(0)
+            with cw.tuned(CW_HOST_SHARED_STREAMS=shared, CW_HOST_CHUNK_MB=32):
+                for pinned in (False, True):
+                    dig, sizes, offsets, packed = cw.hash_and_compress_packed("skein512", "lz4", a, bs, pinned=pinned)
+                    assert np.array_equal(dig, odig) and np.array_equal(sizes, osz), (shared, pinned)
+                    assert int(offsets[nb]) == len(want) and packed.tobytes() == want, (shared, pinned)
+        except BaseException as e:   # noqa: BLE001 (reported in the main thread)
+            errors.append((shared, repr(e)))
+
+    for shared in (1, 0):
+        t = threading.Thread(target=run, args=(shared,))
+        t.start()
+        t.join()
+    assert not errors, errors
